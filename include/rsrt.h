@@ -1,0 +1,150 @@
+/*
+ * rsrt.h — C-ABI of the MI355X path-tracing integrator (librsrt.so).
+ *
+ * Drop-in boundary.  The reference has no FFI: its integrator is the WGSL compute shader
+ * src/shaders/shader.wgsl (entry `main` :1305, `trace_ray` :1213) reached through three wgpu
+ * bind groups that `State::new` builds (src/state.rs:60-649) and `State::render` dispatches
+ * once per displayed frame (src/state.rs:760-833).  The entry points below are that bind-group
+ * contract restated as plain C calls — what a Rust `extern "C"` block in src/state.rs would
+ * bind (INTEGRATION.md shows the stub):
+ *
+ *   bind group 2 (scene storage buffers, state.rs:394-458)        -> rsrt_upload_scene
+ *   bind group 0 bindings 2-5 (sampler, HDRIs, metadata, alias)   -> rsrt_upload_environment
+ *   bind group 1 (camera/resolution/sample_count/env index)       -> arguments of rsrt_render
+ *   bind group 0 binding 1 (cumulative_light_texture, RGBA32F sum) -> the accumulator
+ *   bind group 0 binding 0 (out_texture, RGBA16F mean)             -> rsrt_resolve_mean_f16
+ *   compute_pass.dispatch_workgroups (state.rs:808-824)            -> rsrt_render
+ *   encoder.clear_texture(cumulative) on scene-hash change (:778-786) -> rsrt_accumulator_clear
+ *
+ * Semantics that differ from the reference on purpose:
+ *   - one rsrt_render call may add MANY samples (the reference adds exactly one per frame);
+ *     sample k of pixel p always uses the reference's RNG seed (pixel_index, k)
+ *     (shader.wgsl:1309-1312), so any split over calls / tiles / GPUs gives the same image;
+ *   - max_bounces is a run-time argument (the reference's constant is 10, shader.wgsl:232);
+ *   - dev_index is fixed at 1 (normal render); the debug views 2/3 are out of scope.
+ *
+ * Threading: a context is used from one thread at a time, like `State`.  All functions return
+ * an rsrt_status (0 = ok) and never throw/abort across the boundary; rsrt_last_error() gives
+ * the message.  No CPU fallback exists: without a gfx950 device rsrt_context_create fails.
+ */
+#ifndef RSRT_H
+#define RSRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rsrt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rsrt_status {
+    RSRT_OK = 0,
+    RSRT_ERR_INVALID_ARGUMENT = 1,
+    RSRT_ERR_NO_DEVICE = 2,
+    RSRT_ERR_HIP = 3,
+    RSRT_ERR_NOT_READY = 4, /* scene or environment not uploaded / accumulator missing */
+    RSRT_ERR_OUT_OF_MEMORY = 5
+} rsrt_status;
+
+typedef struct rsrt_context rsrt_context;
+
+/* flags of rsrt_render */
+enum {
+    /* Traverse exactly as shader.wgsl:469-564 does: no t-pruning of nodes, closest-hit shadow
+     * query.  Default (0) prunes nodes entered beyond the current best hit and lets the NEE
+     * shadow query stop at its first hit — both leave every pixel value unchanged. */
+    RSRT_FLAG_REFERENCE_TRAVERSAL = 1u
+};
+
+/* Counters of the last rsrt_render call (and cumulative since context creation). */
+typedef struct rsrt_stats {
+    uint64_t paths;        /* camera paths started */
+    uint64_t ext_rays;     /* calls of cast_ray (shader.wgsl:1221) */
+    uint64_t shadow_rays;  /* NEE queries actually issued (shader.wgsl:1246-1250) */
+    double kernel_ms;      /* HIP-event time of the integrator kernel(s) on the launch stream */
+    uint64_t total_paths, total_ext_rays, total_shadow_rays;
+    double total_kernel_ms;
+    uint32_t launches;     /* kernel launches of the last call */
+    uint32_t _pad;
+} rsrt_stats;
+
+/* -- context: State::new's device acquisition (state.rs:60-98) ------------------------------ */
+rsrt_status rsrt_context_create(int device_index, rsrt_context **out);
+void rsrt_context_destroy(rsrt_context *ctx);
+/* Message of the last failing call on ctx; with ctx == NULL, of the last failing
+ * rsrt_context_create on this thread. Never NULL. */
+const char *rsrt_last_error(const rsrt_context *ctx);
+
+/* -- scene: bind group 2, the eight storage buffers (state.rs:394-458) -----------------------
+ * Arrays are in the layouts of rsrt_types.h; the library copies and re-lays them out for the
+ * device, the caller keeps ownership.  Any array may be empty (pointer ignored when count 0)
+ * except bvh_nodes.  Indices are validated; an out-of-range index is RSRT_ERR_INVALID_ARGUMENT. */
+rsrt_status rsrt_upload_scene(rsrt_context *ctx,
+                              const rsrt_material *materials, uint32_t n_materials,
+                              const rsrt_sphere *spheres, uint32_t n_spheres,
+                              const rsrt_plane *planes, uint32_t n_planes,
+                              const rsrt_vec3 *vertices, uint32_t n_vertices,
+                              const rsrt_vec3 *normals, uint32_t n_normals,
+                              const rsrt_triangle *triangles, uint32_t n_triangles,
+                              const rsrt_primitive_info *primitives, uint32_t n_primitives,
+                              const rsrt_bvh_node *bvh_nodes, uint32_t n_bvh_nodes);
+
+/* -- environment: bind group 0 bindings 3-5 (state.rs:119-132, environments.rs:19-64) --------
+ * slot = index into the reference's binding_array / `environments` array.  rgba: width*height*4
+ * f32, rows top to bottom, alpha ignored (texture.rs:112-115 writes 0).  alias: width*height
+ * entries as AliasTable::build_by_luminance produces (rsrt_host.h has that builder). */
+rsrt_status rsrt_upload_environment(rsrt_context *ctx, uint32_t slot, uint32_t width, uint32_t height,
+                                    const float *rgba, const rsrt_alias_entry *alias);
+
+/* -- multi-GPU framebuffer ownership (no reference counterpart) ---------------
+ * The frame is cut into tile_w x tile_h pixel tiles numbered row-major; this context renders
+ * tile t iff t % world_size == rank and leaves every other pixel of the accumulator untouched.
+ * Default: rank 0 of 1 (whole frame). */
+rsrt_status rsrt_set_partition(rsrt_context *ctx, uint32_t rank, uint32_t world_size, uint32_t tile_w, uint32_t tile_h);
+
+/* -- accumulator: cumulative_light_texture (hdr.rs:217-223) ----------------------------------
+ * Library-owned W*H RGBA32F sum on the device, (re)allocated and zeroed when the resolution
+ * changes (State::resize).  rsrt_accumulator_bind lets the caller own it instead (a device
+ * pointer of width*height*4 floats, e.g. a torch tensor that a RCCL reduce will read); pass NULL
+ * to go back to the internal one. */
+rsrt_status rsrt_accumulator_resize(rsrt_context *ctx, uint32_t width, uint32_t height);
+rsrt_status rsrt_accumulator_bind(rsrt_context *ctx, void *device_rgba32f, uint32_t width, uint32_t height);
+rsrt_status rsrt_accumulator_clear(rsrt_context *ctx);
+rsrt_status rsrt_accumulator_download(rsrt_context *ctx, float *host_rgba, size_t n_floats);
+/* out_texture: mean = sum / sample_total rounded to binary16 (shader.wgsl:1369-1372) */
+rsrt_status rsrt_resolve_mean_f16(rsrt_context *ctx, uint32_t sample_total, uint16_t *host_rgba16f, size_t n_halfs);
+
+/* -- render: State::render's compute pass (state.rs:808-824), batched over samples -----------
+ * Adds samples [sample_begin, sample_begin + sample_count) of every owned pixel into the
+ * accumulator (alpha := 1), in increasing sample order per pixel, on `hip_stream`
+ * (a hipStream_t, NULL = the context's own stream).  Asynchronous; rsrt_synchronize or
+ * rsrt_accumulator_download/rsrt_get_stats wait for it. */
+rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t width, uint32_t height,
+                        uint32_t sample_begin, uint32_t sample_count, uint32_t max_bounces,
+                        uint32_t environment_index, uint32_t flags, void *hip_stream);
+rsrt_status rsrt_synchronize(rsrt_context *ctx);
+rsrt_status rsrt_get_stats(rsrt_context *ctx, rsrt_stats *out);
+
+/* -- ray-query probe: cast_ray / cast_ray_bvh for a batch of rays (shader.wgsl:469-601) -------
+ * Exists for parity tests of traversal + intersection without the RNG: out records are
+ * {did_hit u32, distance f32, hit_point 3xf32, normal 3xf32, material_id u32} = 36 bytes.
+ * mode 0 = cast_ray (BVH then brute-force fallback), 1 = cast_ray_bvh. Host pointers. */
+typedef struct rsrt_hit {
+    uint32_t did_hit;
+    float distance;
+    float hit_point[3];
+    float normal[3];
+    uint32_t material_id;
+} rsrt_hit;
+rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n_rays, const float *origins_xyz, const float *directions_xyz,
+                           uint32_t mode, uint32_t flags, rsrt_hit *out);
+
+/* Library / device description, for logs: "librsrt <version>; <device name>; <CUs> CUs". */
+const char *rsrt_describe(rsrt_context *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSRT_H */

@@ -1,0 +1,57 @@
+"""In-tree native builds: librsrt_host.so (g++, CPU preprocessing) and librsrt.so (hipcc, gfx950)."""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(os.path.dirname(PKG), "include")
+
+HOST_SOURCES = ["host/bvh_build.cpp", "host/preprocess.cpp", "host/scene_load.cpp", "host/image_io.cpp"]
+HIP_SOURCES = ["hip/rsrt_api.hip"]
+HOST_LIB = os.path.join(PKG, "librsrt_host.so")
+HIP_LIB = os.path.join(PKG, "librsrt.so")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _deps(subdir):
+    out = [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
+    d = os.path.join(CSRC, subdir)
+    out += [os.path.join(d, f) for f in os.listdir(d)]
+    return out
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build_host(force=False):
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if force or _newer(HOST_LIB, _deps("host")):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wextra", "-o", HOST_LIB] + srcs)
+    return HOST_LIB
+
+
+def hipcc_path():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_hip(force=False, extra_flags=()):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    if force or _newer(HIP_LIB, _deps("hip")):
+        _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+              "-fno-fast-math", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", INCLUDE, "-o", HIP_LIB] + list(extra_flags) + srcs)
+    return HIP_LIB
+
+
+def build_all(force=False):
+    return build_host(force), build_hip(force)
