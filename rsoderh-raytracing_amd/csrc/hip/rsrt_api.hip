@@ -1,0 +1,911 @@
+// rsrt_api.hip — kernels + C-ABI of librsrt.so (include/rsrt.h).  gfx950 only.
+//
+// Kernel design:
+//  rt_render_kernel   persistent path-tracing kernel.  A workgroup is 4 waves; every WAVE pulls
+//                     chunks (one owned framebuffer tile x a block of sample indices) from one
+//                     global atomic counter.  Lanes own one path each; when a lane's path ends it
+//                     is refilled with the next (pixel, sample) of the wave's chunk — work is
+//                     handed to the idle lanes with a wave64 ballot + prefix popcount, no LDS or
+//                     atomics involved.  Each finished path stores its radiance to the sample
+//                     buffer [sample][pixel slot]; nothing is accumulated in flight, so any lane
+//                     may take any sample and the result cannot depend on scheduling.
+//  rt_resolve_kernel  adds the buffered samples of every owned pixel into the RGBA32F
+//                     accumulator in increasing sample order — the exact f32 sum that
+//                     `sample_count` successive reference frames produce (shader.wgsl:1367-1371).
+//  rt_cast_rays_kernel the ray-query probe.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/rsrt.h"
+#include "rt_device.h"
+
+#define RT_BLOCK 256
+#define RT_WAVE 64
+
+struct RenderParams {
+    DevScene scene;
+    DevEnv env;
+    float cam_pos[3];
+    float cam_rot[9]; // columns
+    float fov_y;
+    uint32_t width, height;
+    uint32_t sample_begin, sample_count; // of this pass
+    uint32_t max_bounces, flags;
+    uint32_t tile_w, tile_h, tiles_x, n_tiles, rank, world, n_owned_tiles;
+    uint32_t samples_per_chunk, n_sblocks, n_chunks;
+    uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
+    float *sample_buf;
+    unsigned int *work_counter;
+    unsigned long long *stats; // paths, ext_rays, shadow_rays
+};
+
+template <bool LDS>
+__device__ __forceinline__ SceneView<LDS> make_view(const DevScene &sc);
+
+template <>
+__device__ __forceinline__ SceneView<true> make_view<true>(const DevScene &sc)
+{
+    SceneView<true> v;
+    v.o_nodes = 0;
+    v.o_prims = v.o_nodes + 2u * sc.n_nodes;
+    v.o_trin = v.o_prims + 4u * sc.n_prims;
+    v.o_mats = v.o_trin + 3u * sc.n_tris;
+    v.o_fbs = v.o_mats + 4u * sc.n_materials;
+    v.o_fbp = v.o_fbs + 4u * sc.n_spheres;
+    return v;
+}
+template <>
+__device__ __forceinline__ SceneView<false> make_view<false>(const DevScene &sc)
+{
+    return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes};
+}
+
+// Copies the scene image into LDS (the six arrays are contiguous in one device allocation, in
+// the order make_view<true> assumes).
+__device__ __forceinline__ void stage_scene_lds(const DevScene &sc)
+{
+    for (uint32_t i = threadIdx.x; i < sc.lds_float4s; i += blockDim.x) rt_smem[i] = sc.nodes[i];
+    __syncthreads();
+}
+
+struct PathState {
+    V3 o, d, throughput, light;
+    float last_pdf;
+    uint32_t rng, bounce, slot; // slot = float index / 3 into the sample buffer
+};
+
+// shader.wgsl:1305-1364: seed, jitter, camera ray
+__device__ __forceinline__ void start_path(const RenderParams &P, uint32_t px, uint32_t py, uint32_t sample, PathState &s)
+{
+    uint32_t pixel_index = py * P.width + px;
+    uint32_t rng = 0;
+    salt_rng(rng, pixel_index);
+    salt_rng(rng, sample);
+    float angle = random_uniform(rng) * 2.0f * 3.1415926f; // random_in_circle_uniform :627-631
+    float cx = rsrt_cosf(angle), cy = rsrt_sinf(angle);
+    float rad = rsrt_sqrtf(random_uniform(rng));
+    float fx = (float)px + cx * rad, fy = (float)py + cy * rad;
+    float sx = ((fx / (float)P.width) * 2.0f - 1.0f) * 1.0f;
+    float sy = ((fy / (float)P.height) * 2.0f - 1.0f) * -1.0f;
+    float m = rsrt_sinf(P.fov_y / 2.0f);
+    float aspect = (float)P.width / (float)P.height;
+    V3 rcs = v3(sx * m * aspect, sy * m, -1.0f);
+    V3 c0 = v3(P.cam_rot[0], P.cam_rot[1], P.cam_rot[2]), c1 = v3(P.cam_rot[3], P.cam_rot[4], P.cam_rot[5]),
+       c2 = v3(P.cam_rot[6], P.cam_rot[7], P.cam_rot[8]);
+    s.o = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    s.d = normalize(mat3_mul(c0, c1, c2, rcs));
+    s.throughput = v3(1, 1, 1);
+    s.light = v3(0, 0, 0);
+    s.last_pdf = 1.0f;
+    s.rng = rng;
+    s.bounce = 0;
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
+{
+    const DevScene &sc = P.scene;
+    if (LDS) stage_scene_lds(sc);
+    const SceneView<LDS> S = make_view<LDS>(sc);
+    uint32_t *stack = reinterpret_cast<uint32_t *>(rt_smem + sc.lds_float4s) + threadIdx.x;
+    const uint32_t stride = RT_BLOCK;
+    const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
+    const bool prune = !(P.flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
+    const uint32_t tile_px = P.tile_w * P.tile_h;
+
+    // wave-uniform chunk cursor
+    uint32_t chunk_next = 0, chunk_left = 0, chunk_tile_slot0 = 0, chunk_tx0 = 0, chunk_ty0 = 0, chunk_s0 = 0;
+    bool exhausted = false;
+
+    PathState ps;
+    bool active = false;
+    unsigned long long n_paths = 0, n_ext = 0, n_shadow = 0;
+
+    for (;;) {
+        // ---------------- refill idle lanes from the wave's chunk (ballot + prefix popcount)
+        while (!exhausted) {
+            unsigned long long need = __ballot(!active);
+            if (need == 0ull) break;
+            if (chunk_left == 0u) {
+                uint32_t c = 0;
+                if (lane == (uint32_t)__builtin_ctzll(need)) c = atomicAdd(P.work_counter, 1u);
+                c = __builtin_amdgcn_readlane((int)c, __builtin_ctzll(need));
+                if (c >= P.n_chunks) { exhausted = true; break; }
+                uint32_t j = c / P.n_sblocks, b = c % P.n_sblocks; // owned-tile ordinal, sample block
+                uint32_t t = j * P.world + P.rank;
+                chunk_tx0 = (t % P.tiles_x) * P.tile_w;
+                chunk_ty0 = (t / P.tiles_x) * P.tile_h;
+                chunk_tile_slot0 = j * tile_px;
+                chunk_s0 = b * P.samples_per_chunk;
+                uint32_t ns = min(P.samples_per_chunk, P.sample_count - chunk_s0);
+                chunk_next = 0;
+                chunk_left = ns * tile_px;
+            }
+            uint32_t n_need = (uint32_t)__popcll(need);
+            uint32_t take = min(n_need, chunk_left);
+            uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            if (!active && rank < take) {
+                uint32_t item = chunk_next + rank;
+                uint32_t k = item / tile_px, p = item % tile_px;
+                uint32_t px = chunk_tx0 + p % P.tile_w, py = chunk_ty0 + p / P.tile_w;
+                if (px < P.width && py < P.height) {
+                    uint32_t srel = chunk_s0 + k;
+                    start_path(P, px, py, P.sample_begin + srel, ps);
+                    ps.slot = srel * P.n_slots + chunk_tile_slot0 + p;
+                    active = true;
+                    n_paths++;
+                }
+            }
+            chunk_next += take;
+            chunk_left -= take;
+        }
+        if (__ballot(active) == 0ull) break;
+
+        // ---------------- extension ray: cast_ray (shader.wgsl:1221)
+        Hit hit;
+        hit.t = RT_INFINITY;
+        if (active) {
+            trace_closest(S, sc, ps.o, ps.d, prune, stack, stride, hit);
+            n_ext++;
+        }
+        bool finished = false;
+        bool want_shadow = false;
+        Surface surf;
+        BsdfMaterial mat;
+        EnvironmentSample es;
+        float cos_nee = 0.0f;
+        if (active) {
+            if (!hit.did_hit()) { // escaped: shader.wgsl:1222-1231
+                float u, v;
+                direction_to_equirectangular_uv(ps.d, u, v);
+                V3 sky = sample_env_bilinear(P.env, u, v);
+                float pdf = environment_direction_pdf(P.env, ps.d, u, v);
+                float w = power_heuristic(ps.last_pdf, pdf);
+                ps.light = ps.light + ps.throughput * sky * w;
+                finished = true;
+            } else {
+                surf = resolve_hit(S, hit, ps.o, ps.d);
+                mat = load_material(S, surf.material_id);
+                ps.light = ps.light + ps.throughput * mat.emission; // :1236
+                es = sample_environment(P.env, ps.rng);             // :1240
+                cos_nee = fmax_(0.0f, dot(surf.normal, es.direction));
+                want_shadow = cos_nee > 0.0f && es.pdf > 0.0f;      // :1246-1247
+            }
+        }
+        // ---------------- NEE shadow query: cast_ray_bvh from the hit point (:1249)
+        bool occluded = false;
+        if (active && want_shadow) {
+            Hit sh;
+            if (prune) trace_bvh<true>(S, surf.point, es.direction, true, stack, stride, sh);
+            else trace_bvh<false>(S, surf.point, es.direction, false, stack, stride, sh);
+            occluded = sh.did_hit();
+            n_shadow++;
+        }
+        if (active && !finished) {
+            if (want_shadow && !occluded) { // :1251-1265
+                Frame frame = make_frame(surf.normal);
+                V3 wo = to_frame_local(frame, -ps.d);
+                V3 wi = to_frame_local(frame, es.direction);
+                V3 scattering = bsdf_eval_local(wo, wi, mat);
+                float pdf_bsdf = bsdf_pdf_local(wo, wi, mat);
+                float w = power_heuristic(es.pdf, pdf_bsdf);
+                ps.light = ps.light + ps.throughput * w * es.radiance * scattering * cos_nee / es.pdf;
+            }
+            BsdfSample bs = bsdf_sample(ps.d, surf.normal, mat, ps.rng); // :1270
+            if (bs.dir.x == 0.0f && bs.dir.y == 0.0f && bs.dir.z == 0.0f) {
+                ps.light = bs.scattering; // debug colour overwrites, :1274
+                finished = true;
+            } else if (bs.pdf <= 0.0f) {
+                finished = true;
+            } else {
+                float c = fmax_(0.0f, dot(surf.normal, bs.dir));
+                ps.throughput = ps.throughput * (bs.scattering * (c / bs.pdf));
+                if (length(ps.throughput) < 0.001f) finished = true;
+                else {
+                    ps.last_pdf = bs.pdf;
+                    ps.o = surf.point;
+                    ps.d = bs.dir;
+                }
+            }
+            ps.bounce++;
+            if (ps.bounce >= P.max_bounces) finished = true;
+        }
+        if (active && finished) {
+            float *dst = P.sample_buf + (size_t)ps.slot * 3u;
+            dst[0] = ps.light.x;
+            dst[1] = ps.light.y;
+            dst[2] = ps.light.z;
+            active = false;
+        }
+    }
+
+    // per-wave reduction of the counters, one atomic per wave and counter
+    for (int off = 32; off > 0; off >>= 1) {
+        n_paths += __shfl_down(n_paths, off);
+        n_ext += __shfl_down(n_ext, off);
+        n_shadow += __shfl_down(n_shadow, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&P.stats[0], n_paths);
+        atomicAdd(&P.stats[1], n_ext);
+        atomicAdd(&P.stats[2], n_shadow);
+    }
+}
+
+// total = textureLoad(cumulative) + sample, once per sample in order (shader.wgsl:1367-1371)
+__global__ __launch_bounds__(RT_BLOCK) void rt_resolve_kernel(RenderParams P, float4 *accum)
+{
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= P.n_slots) return;
+    uint32_t tile_px = P.tile_w * P.tile_h;
+    uint32_t j = slot / tile_px, p = slot % tile_px;
+    uint32_t t = j * P.world + P.rank;
+    uint32_t px = (t % P.tiles_x) * P.tile_w + p % P.tile_w, py = (t / P.tiles_x) * P.tile_h + p / P.tile_w;
+    if (px >= P.width || py >= P.height) return;
+    float4 a = accum[(size_t)py * P.width + px];
+    const float *src = P.sample_buf + (size_t)slot * 3u;
+    const size_t step = (size_t)P.n_slots * 3u;
+    for (uint32_t k = 0; k < P.sample_count; k++, src += step) {
+        a.x = a.x + src[0];
+        a.y = a.y + src[1];
+        a.z = a.z + src[2];
+    }
+    a.w = 1.0f;
+    accum[(size_t)py * P.width + px] = a;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uint32_t n, const float *origins, const float *dirs,
+                                                                uint32_t mode, uint32_t flags, rsrt_hit *out)
+{
+    const SceneView<false> S = make_view<false>(sc);
+    uint32_t *stack = reinterpret_cast<uint32_t *>(rt_smem) + threadIdx.x;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+    V3 d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+    const bool prune = !(flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
+    Hit h;
+    if (mode == 0) trace_closest(S, sc, o, d, prune, stack, RT_BLOCK, h);
+    else trace_bvh<false>(S, o, d, prune, stack, RT_BLOCK, h);
+    rsrt_hit r;
+    memset(&r, 0, sizeof r);
+    if (h.did_hit()) {
+        Surface s = resolve_hit(S, h, o, d);
+        r.did_hit = 1;
+        r.distance = h.t;
+        r.hit_point[0] = s.point.x; r.hit_point[1] = s.point.y; r.hit_point[2] = s.point.z;
+        r.normal[0] = s.normal.x; r.normal[1] = s.normal.y; r.normal[2] = s.normal.z;
+        r.material_id = s.material_id;
+    }
+    out[i] = r;
+}
+
+__global__ void rt_mean_f16_kernel(const float4 *accum, size_t n, float inv_is_unused, uint32_t sample_total, ushort4 *out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = accum[i];
+    float cnt = (float)sample_total; // total_light / f32(sample_count + 1), shader.wgsl:1369
+    __half hx = __float2half_rn(a.x / cnt), hy = __float2half_rn(a.y / cnt), hz = __float2half_rn(a.z / cnt), hw = __float2half_rn(1.0f);
+    out[i] = make_ushort4(__half_as_ushort(hx), __half_as_ushort(hy), __half_as_ushort(hz), __half_as_ushort(hw));
+}
+
+// =================================================================== host side
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Env {
+    float4 *rgba = nullptr;
+    uint4 *alias = nullptr;
+    uint32_t width = 0, height = 0;
+};
+
+} // namespace
+
+struct rsrt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    std::string error;
+    std::string description;
+    int cus = 0;
+    // scene
+    float4 *scene_blob = nullptr;
+    DevScene scene{};
+    bool scene_ready = false;
+    // environments
+    std::vector<Env> envs;
+    // partition
+    uint32_t rank = 0, world = 1, tile_w = 16, tile_h = 16;
+    // accumulator
+    float4 *accum = nullptr;      // bound or owned
+    float4 *accum_owned = nullptr;
+    uint32_t acc_w = 0, acc_h = 0;
+    // work buffers
+    float *sample_buf = nullptr;
+    size_t sample_buf_bytes = 0;
+    unsigned int *work_counter = nullptr;
+    unsigned long long *dev_stats = nullptr;
+    // stats
+    rsrt_stats stats{};
+    bool stats_pending = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    std::vector<hipEvent_t> event_pool;
+    int blocks_per_cu_lds = 0, blocks_per_cu_glb = 0;
+    uint32_t launches_pending = 0;
+};
+
+namespace {
+
+rsrt_status fail(rsrt_context *ctx, rsrt_status st, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    else g_create_error = buf;
+    return st;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RSRT_ERR_OUT_OF_MEMORY : RSRT_ERR_HIP, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                              \
+    } while (0)
+
+struct DeviceGuard {
+    explicit DeviceGuard(int dev) { (void)hipSetDevice(dev); }
+};
+
+inline float fmaxh(float a, float b) { return a < b ? b : a; }
+inline float fminh(float a, float b) { return b < a ? b : a; }
+inline float saturateh(float x) { return fminh(fmaxh(x, 0.0f), 1.0f); }
+inline float4 f4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+// record of one primitive (4 float4), see rt_device.h
+void make_sphere_record(const rsrt_sphere &s, float4 *r)
+{
+    r[0] = f4(s.pos[0], s.pos[1], s.pos[2], u2f(PRIM_SPHERE | (s.material_id << 2)));
+    r[1] = f4(s.radius, s.radius * s.radius, 0, 0);
+    r[2] = r[3] = f4(0, 0, 0, 0);
+}
+void make_plane_record(const rsrt_plane &p, float4 *r)
+{
+    r[0] = f4(p.pos[0], p.pos[1], p.pos[2], u2f(PRIM_PLANE | (p.material_id << 2)));
+    r[1] = f4(p.normal[0], p.normal[1], p.normal[2], 0);
+    r[2] = f4(p.base_change_matrix[0][0], p.base_change_matrix[1][0], p.base_change_matrix[2][0], 0); // row x
+    r[3] = f4(p.base_change_matrix[0][2], p.base_change_matrix[1][2], p.base_change_matrix[2][2], 0); // row z
+}
+void make_triangle_record(const rsrt_triangle &t, uint32_t index, const rsrt_vec3 *v, float4 *r)
+{
+    const float *a = v[t.vertex_0].v, *b = v[t.vertex_1].v, *c = v[t.vertex_2].v;
+    r[0] = f4(a[0], a[1], a[2], u2f(PRIM_TRIANGLE | (t.material_id << 2)));
+    r[1] = f4(b[0] - a[0], b[1] - a[1], b[2] - a[2], u2f(index)); // edge_0, shader.wgsl:415
+    r[2] = f4(c[0] - a[0], c[1] - a[1], c[2] - a[2], 0);          // edge_1, :416
+    r[3] = f4(0, 0, 0, 0);
+}
+// make_bsdf_material / surface_f0 / surface_kd / lobe probabilities (shader.wgsl:850-881, :1147-1148)
+void make_material_record(const rsrt_material &m, float4 *r)
+{
+    const float t = saturateh(m.metallic);
+    float f0[3], kd[3];
+    for (int k = 0; k < 3; k++) f0[k] = (1.0f - t) * 0.04f + t * m.color[k];
+    const float maxf0 = fmaxh(f0[0], fmaxh(f0[1], f0[2]));
+    for (int k = 0; k < 3; k++) kd[k] = (m.color[k] * (1.0f - t)) * (1.0f - maxf0);
+    const float alpha = fmaxh(0.001f, m.roughness * m.roughness);
+    const float ps = saturateh(0.2126f * f0[0] + 0.7152f * f0[1] + 0.0722f * f0[2]);
+    r[0] = f4(m.color[0], m.color[1], m.color[2], m.metallic);
+    r[1] = f4(f0[0], f0[1], f0[2], alpha);
+    r[2] = f4(m.emission[0], m.emission[1], m.emission[2], ps);
+    r[3] = f4(kd[0], kd[1], kd[2], 1.0f - ps);
+}
+
+size_t lds_limit_bytes() { return 64 * 1024; }
+
+rsrt_status ensure_accumulator(rsrt_context *ctx, uint32_t w, uint32_t h)
+{
+    if (ctx->accum && ctx->acc_w == w && ctx->acc_h == h) return RSRT_OK;
+    if (ctx->accum && ctx->accum != ctx->accum_owned)
+        return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bound accumulator is %ux%u but %ux%u was requested", ctx->acc_w, ctx->acc_h, w, h);
+    if (ctx->accum_owned) { (void)hipFree(ctx->accum_owned); ctx->accum_owned = nullptr; ctx->accum = nullptr; }
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMalloc(&ctx->accum_owned, (size_t)w * h * sizeof(float4)));
+    HIP_TRY(ctx, hipMemset(ctx->accum_owned, 0, (size_t)w * h * sizeof(float4)));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    ctx->accum = ctx->accum_owned;
+    ctx->acc_w = w;
+    ctx->acc_h = h;
+    return RSRT_OK;
+}
+
+hipEvent_t get_event(rsrt_context *ctx)
+{
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// Folds finished launches' HIP-event times and device counters into ctx->stats.
+rsrt_status collect_stats(rsrt_context *ctx)
+{
+    if (!ctx->stats_pending) return RSRT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double ms = 0;
+    for (auto &pr : ctx->pending_events) {
+        float t = 0;
+        HIP_TRY(ctx, hipEventSynchronize(pr.second));
+        HIP_TRY(ctx, hipEventElapsedTime(&t, pr.first, pr.second));
+        ms += t;
+        ctx->event_pool.push_back(pr.first);
+        ctx->event_pool.push_back(pr.second);
+    }
+    ctx->pending_events.clear();
+    unsigned long long c[3] = {0, 0, 0}; // device counters are cumulative
+    HIP_TRY(ctx, hipMemcpy(c, ctx->dev_stats, sizeof c, hipMemcpyDeviceToHost));
+    ctx->stats.paths = c[0] - ctx->stats.total_paths;
+    ctx->stats.ext_rays = c[1] - ctx->stats.total_ext_rays;
+    ctx->stats.shadow_rays = c[2] - ctx->stats.total_shadow_rays;
+    ctx->stats.kernel_ms = ms;
+    ctx->stats.total_paths = c[0];
+    ctx->stats.total_ext_rays = c[1];
+    ctx->stats.total_shadow_rays = c[2];
+    ctx->stats.total_kernel_ms += ms;
+    ctx->stats.launches = ctx->launches_pending;
+    ctx->launches_pending = 0;
+    ctx->stats_pending = false;
+    return RSRT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
+{
+    if (!out) return fail(nullptr, RSRT_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, RSRT_ERR_NO_DEVICE, "no HIP device available (%s); librsrt has no CPU path", hipGetErrorString(e));
+    if (device_index < 0 || device_index >= n) return fail(nullptr, RSRT_ERR_INVALID_ARGUMENT, "device_index %d out of range [0,%d)", device_index, n);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_index)) != hipSuccess) return fail(nullptr, RSRT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, RSRT_ERR_NO_DEVICE, "device %d is %s; librsrt is built for gfx950 (MI355X) only", device_index, prop.gcnArchName);
+    rsrt_context *ctx = new rsrt_context();
+    ctx->device = device_index;
+    ctx->cus = prop.multiProcessorCount;
+    DeviceGuard g(device_index);
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc(&ctx->work_counter, sizeof(unsigned int))) != hipSuccess ||
+        (e = hipMalloc(&ctx->dev_stats, 3 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(ctx->dev_stats, 0, 3 * sizeof(unsigned long long))) != hipSuccess) {
+        fail(nullptr, RSRT_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return RSRT_ERR_HIP;
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_render_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_cast_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    char buf[256];
+    snprintf(buf, sizeof buf, "librsrt 0.1; %s (%s); %d CUs", prop.name, prop.gcnArchName, ctx->cus);
+    ctx->description = buf;
+    *out = ctx;
+    return RSRT_OK;
+}
+
+void rsrt_context_destroy(rsrt_context *ctx)
+{
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &pr : ctx->pending_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipFree(ctx->scene_blob);
+    for (auto &e : ctx->envs) { (void)hipFree(e.rgba); (void)hipFree(e.alias); }
+    (void)hipFree(ctx->accum_owned);
+    (void)hipFree(ctx->sample_buf);
+    (void)hipFree(ctx->work_counter);
+    (void)hipFree(ctx->dev_stats);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *rsrt_last_error(const rsrt_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+const char *rsrt_describe(rsrt_context *ctx) { return ctx ? ctx->description.c_str() : "librsrt 0.1"; }
+
+rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials, uint32_t n_materials, const rsrt_sphere *spheres,
+                              uint32_t n_spheres, const rsrt_plane *planes, uint32_t n_planes, const rsrt_vec3 *vertices,
+                              uint32_t n_vertices, const rsrt_vec3 *normals, uint32_t n_normals, const rsrt_triangle *triangles,
+                              uint32_t n_triangles, const rsrt_primitive_info *primitives, uint32_t n_primitives,
+                              const rsrt_bvh_node *nodes, uint32_t n_nodes)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    if (n_nodes == 0 || !nodes) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh_nodes is empty");
+    if ((n_materials && !materials) || (n_spheres && !spheres) || (n_planes && !planes) || (n_vertices && !vertices) ||
+        (n_normals && !normals) || (n_triangles && !triangles) || (n_primitives && !primitives))
+        return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "a non-empty array has a NULL pointer");
+    if (n_materials >= (1u << 30)) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "too many materials");
+    // ---- validate every index the kernels will follow
+    for (uint32_t i = 0; i < n_spheres; i++)
+        if (spheres[i].material_id >= n_materials) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "sphere %u: material_id %u out of range", i, spheres[i].material_id);
+    for (uint32_t i = 0; i < n_planes; i++)
+        if (planes[i].material_id >= n_materials) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "plane %u: material_id %u out of range", i, planes[i].material_id);
+    for (uint32_t i = 0; i < n_triangles; i++) {
+        const rsrt_triangle &t = triangles[i];
+        if (t.material_id >= n_materials) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "triangle %u: material_id %u out of range", i, t.material_id);
+        if (t.vertex_0 >= n_vertices || t.vertex_1 >= n_vertices || t.vertex_2 >= n_vertices)
+            return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "triangle %u: vertex index out of range", i);
+        if (t.normal_0 >= n_normals || t.normal_1 >= n_normals || t.normal_2 >= n_normals)
+            return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "triangle %u: normal index out of range", i);
+    }
+    for (uint32_t i = 0; i < n_primitives; i++) {
+        const rsrt_primitive_info &p = primitives[i];
+        uint32_t lim = p.primitive_type == 0 ? n_spheres : (p.primitive_type == 1 ? n_planes : (p.primitive_type == 2 ? n_triangles : 0));
+        if (p.index >= lim) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "primitive %u: type %u index %u out of range", i, p.primitive_type, p.index);
+    }
+    // tree shape: pre-order layout (children after their parent) => traversal terminates
+    uint32_t depth = 0;
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> st; // node, depth
+        std::vector<uint8_t> seen(n_nodes, 0);
+        st.push_back({0u, 0u});
+        while (!st.empty()) {
+            auto [i, d] = st.back();
+            st.pop_back();
+            if (seen[i]) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh node %u reachable twice", i);
+            seen[i] = 1;
+            depth = std::max(depth, d);
+            const rsrt_bvh_node &nd = nodes[i];
+            if (nd.primitives_len > 0) {
+                if (nd.primitives_len > 0xffffu || (uint64_t)nd.primitives_or_second_child_index + nd.primitives_len > n_primitives)
+                    return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh leaf %u: primitive range out of bounds", i);
+            } else {
+                uint32_t second = nd.primitives_or_second_child_index;
+                if (nd.split_axis > 2 || i + 1 >= n_nodes || second <= i + 1 || second >= n_nodes)
+                    return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh interior node %u: bad child index / axis", i);
+                st.push_back({second, d + 1});
+                st.push_back({i + 1, d + 1});
+            }
+        }
+    }
+    // ---- build the device image: nodes | prims | tri normals | materials | fb spheres | fb planes
+    const size_t n_f4 = 2ull * n_nodes + 4ull * n_primitives + 3ull * n_triangles + 4ull * n_materials + 4ull * n_spheres + 4ull * n_planes;
+    std::vector<float4> img(n_f4);
+    float4 *p = img.data();
+    float4 *p_nodes = p;
+    for (uint32_t i = 0; i < n_nodes; i++, p += 2) {
+        const rsrt_bvh_node &nd = nodes[i];
+        p[0] = f4(nd.bounds_min[0], nd.bounds_min[1], nd.bounds_min[2], u2f(nd.primitives_or_second_child_index));
+        p[1] = f4(nd.bounds_max[0], nd.bounds_max[1], nd.bounds_max[2], u2f(nd.primitives_len | (nd.split_axis << 16)));
+    }
+    float4 *p_prims = p;
+    for (uint32_t i = 0; i < n_primitives; i++, p += 4) {
+        const rsrt_primitive_info &pi = primitives[i];
+        if (pi.primitive_type == 0) make_sphere_record(spheres[pi.index], p);
+        else if (pi.primitive_type == 1) make_plane_record(planes[pi.index], p);
+        else make_triangle_record(triangles[pi.index], pi.index, vertices, p);
+    }
+    float4 *p_trin = p;
+    for (uint32_t i = 0; i < n_triangles; i++, p += 3) {
+        const float *a = normals[triangles[i].normal_0].v, *b = normals[triangles[i].normal_1].v, *c = normals[triangles[i].normal_2].v;
+        p[0] = f4(a[0], a[1], a[2], b[0]);
+        p[1] = f4(b[1], b[2], c[0], c[1]);
+        p[2] = f4(c[2], 0, 0, 0);
+    }
+    float4 *p_mats = p;
+    for (uint32_t i = 0; i < n_materials; i++, p += 4) make_material_record(materials[i], p);
+    float4 *p_fbs = p;
+    for (uint32_t i = 0; i < n_spheres; i++, p += 4) make_sphere_record(spheres[i], p);
+    float4 *p_fbp = p;
+    for (uint32_t i = 0; i < n_planes; i++, p += 4) make_plane_record(planes[i], p);
+
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scene_blob) { (void)hipFree(ctx->scene_blob); ctx->scene_blob = nullptr; }
+    ctx->scene_ready = false;
+    HIP_TRY(ctx, hipMalloc(&ctx->scene_blob, n_f4 * sizeof(float4)));
+    HIP_TRY(ctx, hipMemcpy(ctx->scene_blob, img.data(), n_f4 * sizeof(float4), hipMemcpyHostToDevice));
+    DevScene &sc = ctx->scene;
+    sc.nodes = ctx->scene_blob + (p_nodes - img.data());
+    sc.prims = ctx->scene_blob + (p_prims - img.data());
+    sc.tri_normals = ctx->scene_blob + (p_trin - img.data());
+    sc.materials = ctx->scene_blob + (p_mats - img.data());
+    sc.fb_spheres = ctx->scene_blob + (p_fbs - img.data());
+    sc.fb_planes = ctx->scene_blob + (p_fbp - img.data());
+    sc.n_nodes = n_nodes; sc.n_prims = n_primitives; sc.n_tris = n_triangles; sc.n_materials = n_materials;
+    sc.n_spheres = n_spheres; sc.n_planes = n_planes;
+    sc.stack_entries = depth + 1;
+    const size_t stack_bytes = (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t);
+    if (stack_bytes > 128 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh depth %u exceeds the supported traversal stack", depth);
+    sc.lds_float4s = (n_f4 * sizeof(float4) + stack_bytes <= lds_limit_bytes()) ? (uint32_t)n_f4 : 0u;
+    ctx->scene_ready = true;
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_upload_environment(rsrt_context *ctx, uint32_t slot, uint32_t width, uint32_t height, const float *rgba,
+                                    const rsrt_alias_entry *alias)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    if (!rgba || !alias || width == 0 || height == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "environment: NULL data or zero size");
+    if ((uint64_t)width * height > 0x7fffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "environment too large");
+    if (slot > 63) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "environment slot %u > 63", slot);
+    const size_t n = (size_t)width * height;
+    for (size_t i = 0; i < n; i++)
+        if (alias[i].alias_index >= n) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "alias entry %zu: alias_index %u out of range", i, alias[i].alias_index);
+    if (ctx->envs.size() <= slot) ctx->envs.resize(slot + 1);
+    Env &e = ctx->envs[slot];
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (e.rgba) { (void)hipFree(e.rgba); e.rgba = nullptr; }
+    if (e.alias) { (void)hipFree(e.alias); e.alias = nullptr; }
+    e.width = e.height = 0;
+    HIP_TRY(ctx, hipMalloc(&e.rgba, n * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc(&e.alias, n * sizeof(uint4)));
+    HIP_TRY(ctx, hipMemcpy(e.rgba, rgba, n * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(e.alias, alias, n * sizeof(uint4), hipMemcpyHostToDevice));
+    e.width = width;
+    e.height = height;
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_set_partition(rsrt_context *ctx, uint32_t rank, uint32_t world_size, uint32_t tile_w, uint32_t tile_h)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    if (world_size == 0 || rank >= world_size) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "rank %u not in [0,%u)", rank, world_size);
+    if (tile_w == 0 || tile_h == 0 || tile_w * tile_h > 4096 || (tile_w * tile_h) % RT_WAVE != 0)
+        return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "tile %ux%u: pixel count must be a multiple of 64 and at most 4096", tile_w, tile_h);
+    ctx->rank = rank; ctx->world = world_size; ctx->tile_w = tile_w; ctx->tile_h = tile_h;
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_accumulator_resize(rsrt_context *ctx, uint32_t width, uint32_t height)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    if (width == 0 || height == 0 || (uint64_t)width * height > 0x7fffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bad resolution %ux%u", width, height);
+    if (ctx->accum && ctx->accum != ctx->accum_owned) { ctx->accum = nullptr; ctx->acc_w = ctx->acc_h = 0; }
+    return ensure_accumulator(ctx, width, height);
+}
+
+rsrt_status rsrt_accumulator_bind(rsrt_context *ctx, void *device_rgba32f, uint32_t width, uint32_t height)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!device_rgba32f) {
+        ctx->accum = ctx->accum_owned;
+        if (!ctx->accum) ctx->acc_w = ctx->acc_h = 0;
+        return RSRT_OK;
+    }
+    if (width == 0 || height == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bad resolution %ux%u", width, height);
+    if ((uintptr_t)device_rgba32f % 16) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "accumulator pointer must be 16-byte aligned");
+    if (ctx->accum_owned) { (void)hipFree(ctx->accum_owned); ctx->accum_owned = nullptr; }
+    ctx->accum = static_cast<float4 *>(device_rgba32f);
+    ctx->acc_w = width;
+    ctx->acc_h = height;
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_accumulator_clear(rsrt_context *ctx)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
+    HIP_TRY(ctx, hipMemsetAsync(ctx->accum, 0, (size_t)ctx->acc_w * ctx->acc_h * sizeof(float4), ctx->stream));
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_accumulator_download(rsrt_context *ctx, float *host_rgba, size_t n_floats)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
+    if (!host_rgba || n_floats != (size_t)ctx->acc_w * ctx->acc_h * 4) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "download: expected %zu floats", (size_t)ctx->acc_w * ctx->acc_h * 4);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(host_rgba, ctx->accum, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_resolve_mean_f16(rsrt_context *ctx, uint32_t sample_total, uint16_t *host, size_t n_halfs)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
+    const size_t n = (size_t)ctx->acc_w * ctx->acc_h;
+    if (!host || n_halfs != n * 4 || sample_total == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "resolve_mean_f16: expected %zu halfs and sample_total > 0", n * 4);
+    ushort4 *tmp = nullptr;
+    HIP_TRY(ctx, hipMalloc(&tmp, n * sizeof(ushort4)));
+    hipLaunchKernelGGL(rt_mean_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->accum, n, 0.0f, sample_total, tmp);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(host, tmp, n * sizeof(ushort4), hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(ctx, RSRT_ERR_HIP, "resolve_mean_f16: %s", hipGetErrorString(e));
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t width, uint32_t height, uint32_t sample_begin,
+                        uint32_t sample_count, uint32_t max_bounces, uint32_t environment_index, uint32_t flags, void *hip_stream)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    if (!camera) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "camera is NULL");
+    if (!ctx->scene_ready) return fail(ctx, RSRT_ERR_NOT_READY, "no scene uploaded");
+    if (environment_index >= ctx->envs.size() || !ctx->envs[environment_index].rgba) return fail(ctx, RSRT_ERR_NOT_READY, "environment %u not uploaded", environment_index);
+    if (width == 0 || height == 0 || (uint64_t)width * height > 0x7fffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bad resolution %ux%u", width, height);
+    if ((uint64_t)sample_begin + sample_count > 0xffffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "sample range overflows u32");
+    if (flags & ~(uint32_t)RSRT_FLAG_REFERENCE_TRAVERSAL) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
+    hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
+    rsrt_status st = ensure_accumulator(ctx, width, height);
+    if (st) return st;
+    if (ctx->pending_events.size() >= 64) { st = collect_stats(ctx); if (st) return st; } // bounds the event pool
+    if (sample_count == 0) return RSRT_OK;
+
+    RenderParams P;
+    memset(&P, 0, sizeof P);
+    P.scene = ctx->scene;
+    const Env &env = ctx->envs[environment_index];
+    P.env.rgba = env.rgba; P.env.alias = env.alias; P.env.width = env.width; P.env.height = env.height;
+    memcpy(P.cam_pos, camera->pos, 12);
+    for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) P.cam_rot[3 * j + k] = camera->rot_transform[j][k];
+    P.fov_y = camera->fov_y;
+    P.width = width; P.height = height;
+    P.max_bounces = max_bounces; P.flags = flags;
+    P.tile_w = ctx->tile_w; P.tile_h = ctx->tile_h;
+    P.tiles_x = (width + P.tile_w - 1) / P.tile_w;
+    const uint32_t tiles_y = (height + P.tile_h - 1) / P.tile_h;
+    P.n_tiles = P.tiles_x * tiles_y;
+    P.rank = ctx->rank; P.world = ctx->world;
+    P.n_owned_tiles = P.n_tiles > P.rank ? (P.n_tiles - P.rank + P.world - 1) / P.world : 0;
+    const uint32_t tile_px = P.tile_w * P.tile_h;
+    if ((uint64_t)P.n_owned_tiles * tile_px > 0x7fffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "frame too large");
+    P.n_slots = P.n_owned_tiles * tile_px;
+    P.work_counter = ctx->work_counter;
+    P.stats = ctx->dev_stats;
+    if (P.n_slots == 0) return RSRT_OK;
+
+    // sample buffer: [samples of this pass][slot][3]; passes bound its size
+    size_t budget = 16ull << 30;
+    if (const char *e = getenv("RSRT_SAMPLE_BUFFER_MB")) { long v = atol(e); if (v > 0) budget = (size_t)v << 20; }
+    const size_t per_sample = (size_t)P.n_slots * 3 * sizeof(float);
+    uint32_t pass_samples = (uint32_t)std::max<size_t>(1, std::min<size_t>(sample_count, budget / per_sample));
+    const size_t need = per_sample * pass_samples;
+    if (need > ctx->sample_buf_bytes) {
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        if (ctx->sample_buf) { (void)hipFree(ctx->sample_buf); ctx->sample_buf = nullptr; ctx->sample_buf_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->sample_buf, need));
+        ctx->sample_buf_bytes = need;
+    }
+    P.sample_buf = ctx->sample_buf;
+
+    const bool lds = P.scene.lds_float4s != 0;
+    const size_t smem = (size_t)P.scene.lds_float4s * sizeof(float4) + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t);
+    int &bpc = lds ? ctx->blocks_per_cu_lds : ctx->blocks_per_cu_glb;
+    if (bpc == 0) {
+        int nb = 0;
+        hipError_t e = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_render_kernel<true>, RT_BLOCK, smem)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_render_kernel<false>, RT_BLOCK, smem);
+        if (e != hipSuccess || nb <= 0) nb = 2;
+        bpc = std::min(nb, 8);
+    }
+
+    hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
+    HIP_TRY(ctx, hipEventRecord(e0, stream));
+    for (uint32_t done = 0; done < sample_count; done += pass_samples) {
+        P.sample_begin = sample_begin + done;
+        P.sample_count = std::min(pass_samples, sample_count - done);
+        if (max_bounces > 0) {
+            // chunk = one tile x samples_per_chunk samples; enough chunks to balance the tail
+            P.samples_per_chunk = std::max(1u, std::min(P.sample_count, 2048u / tile_px ? 2048u / tile_px : 1u));
+            P.n_sblocks = (P.sample_count + P.samples_per_chunk - 1) / P.samples_per_chunk;
+            const uint64_t n_chunks = (uint64_t)P.n_owned_tiles * P.n_sblocks;
+            if (n_chunks > 0xffffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "too many work chunks");
+            P.n_chunks = (uint32_t)n_chunks;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, sizeof(unsigned int), stream));
+            const uint32_t waves_wanted = (uint32_t)std::min<uint64_t>(n_chunks, 0x7fffffffull);
+            uint32_t grid = std::min<uint32_t>((waves_wanted + 3) / 4, (uint32_t)(ctx->cus * bpc));
+            grid = std::max(grid, 1u);
+            if (lds) hipLaunchKernelGGL(rt_render_kernel<true>, dim3(grid), dim3(RT_BLOCK), smem, stream, P);
+            else hipLaunchKernelGGL(rt_render_kernel<false>, dim3(grid), dim3(RT_BLOCK), smem, stream, P);
+            HIP_TRY(ctx, hipGetLastError());
+            ctx->launches_pending++;
+        } else {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->sample_buf, 0, per_sample * P.sample_count, stream));
+        }
+        hipLaunchKernelGGL(rt_resolve_kernel, dim3((P.n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, P, ctx->accum);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->launches_pending++;
+    }
+    HIP_TRY(ctx, hipEventRecord(e1, stream));
+    ctx->pending_events.push_back({e0, e1});
+    ctx->stats_pending = true;
+    if (stream != ctx->stream) {
+        // keep the context's own stream ordered after work submitted on the caller's stream
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e1, 0));
+    }
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_synchronize(rsrt_context *ctx)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_get_stats(rsrt_context *ctx, rsrt_stats *out)
+{
+    if (!ctx || !out) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    rsrt_status st = collect_stats(ctx);
+    if (st) return st;
+    *out = ctx->stats;
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, const float *dirs, uint32_t mode, uint32_t flags,
+                           rsrt_hit *out)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    if (!ctx->scene_ready) return fail(ctx, RSRT_ERR_NOT_READY, "no scene uploaded");
+    if (n == 0) return RSRT_OK;
+    if (!origins || !dirs || !out || mode > 1) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: bad arguments");
+    float *d_o = nullptr, *d_d = nullptr;
+    rsrt_hit *d_h = nullptr;
+    hipError_t e = hipMalloc(&d_o, (size_t)n * 12);
+    if (e == hipSuccess) e = hipMalloc(&d_d, (size_t)n * 12);
+    if (e == hipSuccess) e = hipMalloc(&d_h, (size_t)n * sizeof(rsrt_hit));
+    if (e == hipSuccess) e = hipMemcpy(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d, dirs, (size_t)n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const size_t smem = (size_t)ctx->scene.stack_entries * RT_BLOCK * sizeof(uint32_t);
+        hipLaunchKernelGGL(rt_cast_rays_kernel, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), smem, ctx->stream, ctx->scene, n, d_o, d_d, mode, flags, d_h);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_h, (size_t)n * sizeof(rsrt_hit), hipMemcpyDeviceToHost);
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h);
+    if (e != hipSuccess) return fail(ctx, RSRT_ERR_HIP, "cast_rays: %s", hipGetErrorString(e));
+    return RSRT_OK;
+}
+
+} // extern "C"

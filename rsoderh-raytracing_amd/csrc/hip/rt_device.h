@@ -1,0 +1,523 @@
+// rt_device.h — device-side scene layout, BVH traversal, intersection, environment and BSDF.
+//
+// What it computes is the reference's WGSL integrator (src/shaders/shader.wgsl; the functions
+// are cited one by one below); how it is organised is for CDNA4:
+//  * the eight storage buffers are re-laid out at upload into 16-byte records that a lane
+//    fetches with ds_read_b128 / global_load_dwordx4:
+//      node      2 x float4  {min.xyz, idx}{max.xyz, len | axis<<16}           (32 B, was 48 B)
+//      prim ref  4 x float4  one record per entry of `primitives`, in leaf order, holding the
+//                            primitive itself (no second indirection) with per-primitive
+//                            constants precomputed (triangle edges, sphere r^2, the two matrix
+//                            rows the plane test uses)
+//      material  4 x float4  BsdfMaterial incl. kd, lobe probabilities (make_bsdf_material,
+//                            surface_kd, luminance are pure functions of the material)
+//      tri normals 3 x float4, fetched once per closest hit, not per test
+//  * hit attributes (normal, hit point) are resolved once after traversal from (t,u,v,prim),
+//    not per candidate — same values, computed once;
+//  * result-preserving traversal options: prune nodes entered beyond the current best t,
+//    any-hit exit for the NEE shadow query (RSRT_FLAG_REFERENCE_TRAVERSAL turns both off).
+#pragma once
+#include "rt_math.h"
+
+#define RT_INFINITY 1.70141183460469231732e+38f // shader.wgsl:235
+#define RT_PI ((float)3.14159)                   // shader.wgsl:239
+#define RT_INV_PI ((float)(1.0 / 3.14159))       // :240, const-evaluated in abstract float
+#define RT_TWO_PI ((float)(2.0 * 3.14159))       // `2 * PI`
+
+enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_TRIANGLE = 2 };
+enum { SRC_BVH = 0, SRC_FB_SPHERE = 1, SRC_FB_PLANE = 2 };
+
+struct DevScene {
+    const float4 *nodes;       // 2 per node
+    const float4 *prims;       // 4 per primitive reference, leaf order
+    const float4 *tri_normals; // 3 per triangle
+    const float4 *materials;   // 4 per material
+    const float4 *fb_spheres;  // 4 per sphere, scene order (cast_ray's brute-force loop)
+    const float4 *fb_planes;   // 4 per plane
+    uint32_t n_nodes, n_prims, n_tris, n_materials, n_spheres, n_planes;
+    uint32_t stack_entries;    // per-lane traversal stack entries (tree depth + 1)
+    uint32_t lds_float4s;      // float4 count of the LDS image (0 = scene stays in global memory)
+};
+
+struct DevEnv {
+    const float4 *rgba;
+    const uint4 *alias; // {probability bits, alias_index, pmf bits, pad}
+    uint32_t width, height;
+};
+
+// Scene accessor: either the LDS image (offsets in float4 units) or global memory.
+template <bool LDS>
+struct SceneView;
+
+extern __shared__ float4 rt_smem[];
+
+template <>
+struct SceneView<true> {
+    uint32_t o_nodes, o_prims, o_trin, o_mats, o_fbs, o_fbp;
+    RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
+    RT_DEV float4 prim(uint32_t i) const { return rt_smem[o_prims + i]; }
+    RT_DEV float4 trin(uint32_t i) const { return rt_smem[o_trin + i]; }
+    RT_DEV float4 mat(uint32_t i) const { return rt_smem[o_mats + i]; }
+    RT_DEV float4 fbs(uint32_t i) const { return rt_smem[o_fbs + i]; }
+    RT_DEV float4 fbp(uint32_t i) const { return rt_smem[o_fbp + i]; }
+};
+template <>
+struct SceneView<false> {
+    const float4 *nodes, *prims, *tri_normals, *materials, *fb_spheres, *fb_planes;
+    RT_DEV float4 node(uint32_t i) const { return nodes[i]; }
+    RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
+    RT_DEV float4 trin(uint32_t i) const { return tri_normals[i]; }
+    RT_DEV float4 mat(uint32_t i) const { return materials[i]; }
+    RT_DEV float4 fbs(uint32_t i) const { return fb_spheres[i]; }
+    RT_DEV float4 fbp(uint32_t i) const { return fb_planes[i]; }
+};
+
+// ------------------------------------------------------------------ RNG (shader.wgsl:605-631)
+RT_DEV uint32_t random_u32_uniform(uint32_t &s)
+{
+    s = s * 747796405u + 2891336453u;
+    uint32_t r = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (r >> 22) ^ r;
+}
+RT_DEV void salt_rng(uint32_t &s, uint32_t salt)
+{
+    s ^= salt;
+    random_u32_uniform(s);
+}
+// f32(r) / 4294967295.0: the divisor rounds to 2^32, so this is the exact scaling by 2^-32
+RT_DEV float random_uniform(uint32_t &s) { return (float)random_u32_uniform(s) * 2.3283064365386963e-10f; }
+
+// ------------------------------------------------------------------ primitive tests
+// Each returns the hit distance or a negative value for "no hit" (all accepted t are >= 1e-5).
+#define RT_NO_HIT (-1.0f)
+
+// cast_ray_sphere, shader.wgsl:295-333
+RT_DEV float sphere_t(V3 o, V3 d, V3 pos, float r2)
+{
+    const float EPSILON = 1.0e-4f;
+    V3 l = o - pos;
+    float a = dot(d, d);
+    float b = 2.0f * dot(d, l);
+    float c = dot(l, l) - r2;
+    float disc = b * b - 4.0f * a * c;
+    float t;
+    if (disc < 0.0f) return RT_NO_HIT;
+    if (disc == 0.0f) {
+        t = -0.5f * b / a;
+    } else {
+        float sq = rsrt_sqrtf(disc);
+        float q = (b > 0.0f) ? -0.5f * (b + sq) : -0.5f * (b - sq);
+        float t0 = q / a, t1 = c / q;
+        if (t0 < EPSILON) t = t1;
+        else if (t1 < EPSILON) t = t0;
+        else t = fmin_(t0, t1);
+    }
+    return (t < EPSILON) ? RT_NO_HIT : t;
+}
+// cast_ray_plane, shader.wgsl:362-391; rx / rz = the x and z rows of base_change_matrix
+RT_DEV float plane_t(V3 o, V3 d, V3 pos, V3 n, V3 rx, V3 rz)
+{
+    float den = dot(n, d);
+    if (fabs_(den) < 0.0001f) return RT_NO_HIT;
+    float t = dot(n, pos - o) / den;
+    if (t < 0.001f) return RT_NO_HIT;
+    V3 il = madd(d, t, o) - pos;
+    float px = __builtin_fmaf(rx.z, il.z, __builtin_fmaf(rx.y, il.y, rx.x * il.x));
+    float pz = __builtin_fmaf(rz.z, il.z, __builtin_fmaf(rz.y, il.y, rz.x * il.x));
+    if (px < 0.0f || 1.0f < px || pz < 0.0f || 1.0f < pz) return RT_NO_HIT;
+    return t;
+}
+// cast_ray_triangle, shader.wgsl:409-444
+RT_DEV float triangle_t(V3 o, V3 d, V3 a, V3 e0, V3 e1, float &u, float &v)
+{
+    V3 op = o - a;
+    V3 p0 = cross(op, e0);
+    V3 p1 = cross(d, e1);
+    float det = dot(e0, p1);
+    float inv = 1.0f / det;
+    if (fabs_(det) < 1.0e-8f) return RT_NO_HIT;
+    u = dot(op, p1) * inv;
+    v = dot(d, p0) * inv;
+    if (u < 0.0f || 1.0f < u) return RT_NO_HIT;
+    if (v < 0.0f || 1.0f < (u + v)) return RT_NO_HIT;
+    float t = dot(e1, p0) * inv;
+    return (t < 1.0e-5f) ? RT_NO_HIT : t;
+}
+
+struct Hit {
+    float t;       // RT_INFINITY while nothing is hit
+    uint32_t ref;  // record index in the array named by src
+    uint32_t src;  // SRC_*
+    float u, v;
+    RT_DEV bool did_hit() const { return t < RT_INFINITY; }
+};
+
+struct Surface {
+    V3 point, normal;
+    uint32_t material_id;
+};
+
+template <class View>
+RT_DEV float4 hit_record(const View &S, const Hit &h, uint32_t k)
+{
+    uint32_t i = 4u * h.ref + k;
+    return h.src == SRC_BVH ? S.prim(i) : (h.src == SRC_FB_SPHERE ? S.fbs(i) : S.fbp(i));
+}
+
+// The HitInfo fields the shader fills at every accepted test (shader.wgsl:335-359, :393-405,
+// :446-465), computed once for the closest hit.
+template <class View>
+RT_DEV Surface resolve_hit(const View &S, const Hit &h, V3 o, V3 d)
+{
+    Surface s;
+    float4 r0 = hit_record(S, h, 0);
+    uint32_t tag = as_u(r0.w);
+    uint32_t type = tag & 3u;
+    s.material_id = tag >> 2;
+    s.point = madd(d, h.t, o);
+    V3 p0 = v3(r0.x, r0.y, r0.z);
+    if (type == PRIM_TRIANGLE) {
+        uint32_t tri = as_u(hit_record(S, h, 1).w);
+        float4 a = S.trin(3u * tri), b = S.trin(3u * tri + 1u), c = S.trin(3u * tri + 2u);
+        V3 n0 = v3(a.x, a.y, a.z), n1 = v3(a.w, b.x, b.y), n2 = v3(b.z, b.w, c.x);
+        V3 n = normalize((1.0f - h.u - h.v) * n0 + h.u * n1 + h.v * n2);
+        if (dot(n, d) > 0.0f) n = n * -1.0f;
+        s.normal = n;
+    } else if (type == PRIM_SPHERE) {
+        float r2 = hit_record(S, h, 1).y;
+        V3 n = normalize(s.point - p0);
+        V3 co = p0 - o;
+        if (dot(co, co) - r2 < 1.0e-6f) n = n * -1.0f;
+        s.normal = n;
+    } else {
+        float4 r1 = hit_record(S, h, 1);
+        V3 n = v3(r1.x, r1.y, r1.z);
+        if (dot(o, n) < 0.0f) n = n * -1.0f; // origin NOT plane-relative, shader.wgsl:394
+        s.normal = n;
+    }
+    return s;
+}
+
+template <class View>
+RT_DEV float test_record(const View &S, uint32_t rec, uint32_t src, V3 o, V3 d, float &u, float &v)
+{
+    uint32_t i = 4u * rec;
+    float4 r0 = src == SRC_BVH ? S.prim(i) : (src == SRC_FB_SPHERE ? S.fbs(i) : S.fbp(i));
+    float4 r1 = src == SRC_BVH ? S.prim(i + 1) : (src == SRC_FB_SPHERE ? S.fbs(i + 1) : S.fbp(i + 1));
+    uint32_t type = as_u(r0.w) & 3u;
+    V3 p0 = v3(r0.x, r0.y, r0.z);
+    if (type == PRIM_TRIANGLE) {
+        float4 r2 = S.prim(i + 2);
+        return triangle_t(o, d, p0, v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), u, v);
+    } else if (type == PRIM_SPHERE) {
+        return sphere_t(o, d, p0, r1.y);
+    } else {
+        float4 r2 = src == SRC_BVH ? S.prim(i + 2) : S.fbp(i + 2);
+        float4 r3 = src == SRC_BVH ? S.prim(i + 3) : S.fbp(i + 3);
+        return plane_t(o, d, p0, v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), v3(r3.x, r3.y, r3.z));
+    }
+}
+
+// cast_ray_bvh, shader.wgsl:469-564 (+ ray_intersects_bounds :262-293).  Visit order, test
+// order and the strict `<` replacement are the reference's, so ties resolve identically.
+// `stack` points at this lane's column of the LDS stack, entries `stride` dwords apart.
+template <bool ANYHIT, class View>
+RT_DEV void trace_bvh(const View &S, V3 o, V3 d, bool prune, uint32_t *stack, uint32_t stride, Hit &h)
+{
+    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    h.t = RT_INFINITY;
+    h.ref = 0;
+    h.src = SRC_BVH;
+    h.u = h.v = 0.0f;
+    uint32_t sp = 0, cur = 0;
+    for (;;) {
+        float4 n0 = S.node(2u * cur), n1 = S.node(2u * cur + 1u);
+        float t_0 = 0.0f, t_1 = RT_INFINITY;
+        bool inside = true;
+        {
+            float tn = (n0.x - o.x) * inv.x, tf = (n1.x - o.x) * inv.x;
+            if (tn > tf) { float s = tn; tn = tf; tf = s; }
+            if (tn > t_0) t_0 = tn;
+            if (tf < t_1) t_1 = tf;
+            if (t_0 > t_1) inside = false;
+        }
+        if (inside) {
+            float tn = (n0.y - o.y) * inv.y, tf = (n1.y - o.y) * inv.y;
+            if (tn > tf) { float s = tn; tn = tf; tf = s; }
+            if (tn > t_0) t_0 = tn;
+            if (tf < t_1) t_1 = tf;
+            if (t_0 > t_1) inside = false;
+        }
+        if (inside) {
+            float tn = (n0.z - o.z) * inv.z, tf = (n1.z - o.z) * inv.z;
+            if (tn > tf) { float s = tn; tn = tf; tf = s; }
+            if (tn > t_0) t_0 = tn;
+            if (tf < t_1) t_1 = tf;
+            if (t_0 > t_1) inside = false;
+        }
+        if (inside && prune && t_0 > h.t) inside = false;
+        uint32_t idx = as_u(n0.w), la = as_u(n1.w);
+        uint32_t len = la & 0xffffu, axis = la >> 16;
+        bool pop = true;
+        if (inside) {
+            if (len > 0u) {
+                for (uint32_t i = 0; i < len; i++) {
+                    float u, v;
+                    float t = test_record(S, idx + i, SRC_BVH, o, d, u, v);
+                    if (t >= 0.0f && t < h.t) {
+                        h.t = t;
+                        h.ref = idx + i;
+                        h.u = u;
+                        h.v = v;
+                        if (ANYHIT) return;
+                    }
+                }
+            } else {
+                uint32_t near_child, far_child;
+                if (comp(inv, axis) < 0.0f) { near_child = idx; far_child = cur + 1u; }
+                else { near_child = cur + 1u; far_child = idx; }
+                stack[sp * stride] = far_child;
+                sp++;
+                cur = near_child;
+                pop = false;
+            }
+        }
+        if (pop) {
+            if (sp == 0u) break;
+            sp--;
+            cur = stack[sp * stride];
+        }
+    }
+}
+
+// cast_ray, shader.wgsl:567-601: BVH, and only if it missed, every sphere then every plane.
+template <class View>
+RT_DEV void trace_closest(const View &S, const DevScene &sc, V3 o, V3 d, bool prune, uint32_t *stack, uint32_t stride, Hit &h)
+{
+    trace_bvh<false>(S, o, d, prune, stack, stride, h);
+    if (h.did_hit()) return;
+    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+        float u, v;
+        float t = test_record(S, i, SRC_FB_SPHERE, o, d, u, v);
+        if (t >= 0.0f && t < h.t) { h.t = t; h.ref = i; h.src = SRC_FB_SPHERE; }
+    }
+    for (uint32_t i = 0; i < sc.n_planes; i++) {
+        float u, v;
+        float t = test_record(S, i, SRC_FB_PLANE, o, d, u, v);
+        if (t >= 0.0f && t < h.t) { h.t = t; h.ref = i; h.src = SRC_FB_PLANE; }
+    }
+}
+
+// ------------------------------------------------------------------ environment (shader.wgsl:689-831)
+RT_DEV void direction_to_equirectangular_uv(V3 d, float &u, float &v) // :710-714
+{
+    u = rsrt_atan2f(d.z, d.x) * RT_INV_PI * 0.5f + 0.5f;
+    v = 0.5f - rsrt_asinf(d.y) * RT_INV_PI;
+}
+RT_DEV V3 equirectangular_uv_to_direction(float u, float v) // :718-732
+{
+    float phi = (2.0f * u - 1.0f) * RT_PI;
+    float theta = RT_PI * v;
+    float st = rsrt_sinf(theta), ct = rsrt_cosf(theta);
+    return v3(st * rsrt_cosf(phi), ct, st * rsrt_sinf(phi));
+}
+RT_DEV float environment_pixel_solid_angle(float v, const DevEnv &e) // :739-749
+{
+    float theta = RT_PI * v;
+    float sin_t = fmax_(1.0e-6f, rsrt_sinf(theta));
+    float d_phi = RT_TWO_PI / (float)e.width;
+    float d_theta = RT_PI / (float)e.height;
+    return d_phi * d_theta * sin_t;
+}
+RT_DEV uint32_t clamp_texel(float f, uint32_t n)
+{
+    if (!(f > 0.0f)) return 0u;
+    if (f >= (float)(n - 1u)) return n - 1u;
+    return (uint32_t)f;
+}
+// textureSampleLevel(env, sampler, uv, 0).xyz — linear magnification, clamp-to-edge
+// (src/state.rs:134-142), full-precision f32 weights a*(1-f) + b*f
+RT_DEV V3 sample_env_bilinear(const DevEnv &e, float u, float v)
+{
+    float x = u * (float)e.width - 0.5f, y = v * (float)e.height - 0.5f;
+    float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+    float fx = x - xf, fy = y - yf;
+    uint32_t x0 = clamp_texel(xf, e.width), x1 = clamp_texel(xf + 1.0f, e.width);
+    uint32_t y0 = clamp_texel(yf, e.height), y1 = clamp_texel(yf + 1.0f, e.height);
+    float4 t00 = e.rgba[(size_t)y0 * e.width + x0], t10 = e.rgba[(size_t)y0 * e.width + x1];
+    float4 t01 = e.rgba[(size_t)y1 * e.width + x0], t11 = e.rgba[(size_t)y1 * e.width + x1];
+    float gx = 1.0f - fx, gy = 1.0f - fy;
+    V3 top = v3(t00.x, t00.y, t00.z) * gx + v3(t10.x, t10.y, t10.z) * fx;
+    V3 bot = v3(t01.x, t01.y, t01.z) * gx + v3(t11.x, t11.y, t11.z) * fx;
+    return top * gy + bot * fy;
+}
+RT_DEV float environment_direction_pdf(const DevEnv &e, V3 dir, float u, float v) // :753-769 (uv already computed)
+{
+    uint32_t x = min(f2u(u * (float)e.width), e.width - 1u);
+    uint32_t y = min(f2u(v * (float)e.height), e.height - 1u);
+    uint32_t index = x + y * e.width;
+    float pmf = as_f(e.alias[index].z);
+    return pmf / environment_pixel_solid_angle(v, e);
+}
+struct EnvironmentSample {
+    V3 direction, radiance;
+    float pdf;
+};
+RT_DEV EnvironmentSample sample_environment(const DevEnv &e, uint32_t &rng) // :782-820 + :689-706
+{
+    uint32_t length = e.width * e.height;
+    uint32_t index = min(f2u(random_uniform(rng) * (float)length), length - 1u);
+    uint4 entry = e.alias[index];
+    float u2 = random_uniform(rng);
+    uint32_t pick = (u2 < as_f(entry.x)) ? index : entry.y;
+    uint32_t x = pick % e.width, y = pick / e.width;
+    float jx = random_uniform(rng), jy = random_uniform(rng);
+    float u = ((float)x + jx) / (float)e.width;
+    float v = ((float)y + jy) / (float)e.height;
+    EnvironmentSample s;
+    s.direction = equirectangular_uv_to_direction(u, v);
+    s.radiance = sample_env_bilinear(e, u, v);
+    float pmf = (pick == index) ? as_f(entry.z) : as_f(e.alias[pick].z);
+    s.pdf = pmf / environment_pixel_solid_angle(v, e);
+    return s;
+}
+
+// ------------------------------------------------------------------ BSDF (shader.wgsl:55-84, 850-1210)
+struct BsdfMaterial {
+    V3 f0, kd, emission;
+    float alpha, spec_prob, diff_prob;
+};
+template <class View>
+RT_DEV BsdfMaterial load_material(const View &S, uint32_t id)
+{
+    float4 m1 = S.mat(4u * id + 1u), m2 = S.mat(4u * id + 2u), m3 = S.mat(4u * id + 3u);
+    BsdfMaterial m;
+    m.f0 = v3(m1.x, m1.y, m1.z);
+    m.alpha = m1.w;
+    m.emission = v3(m2.x, m2.y, m2.z);
+    m.spec_prob = m2.w;
+    m.kd = v3(m3.x, m3.y, m3.z);
+    m.diff_prob = m3.w;
+    return m;
+}
+struct Frame {
+    V3 tangent, bitangent, normal;
+};
+RT_DEV Frame make_frame(V3 n) // :55-67
+{
+    V3 helper = (fabs_(n.z) < 0.999f) ? v3(0, 0, 1) : v3(1, 0, 0);
+    V3 t = normalize(cross(helper, n));
+    V3 b = cross(n, t);
+    return Frame{t, b, n};
+}
+RT_DEV V3 to_frame_local(const Frame &f, V3 w) { return v3(dot(w, f.tangent), dot(w, f.bitangent), dot(w, f.normal)); }
+RT_DEV V3 to_frame_world(const Frame &f, V3 l) { return normalize(f.tangent * l.x + f.bitangent * l.y + f.normal * l.z); }
+
+RT_DEV float d_ggx(float ndh, float alpha) // :924-928
+{
+    float a2 = alpha * alpha;
+    float den = (ndh * ndh) * (a2 - 1.0f) + 1.0f;
+    return a2 / (RT_PI * den * den);
+}
+RT_DEV float lambda_ggx(float ndv, float alpha) // :1014-1020
+{
+    float ndv2 = ndv * ndv;
+    return (rsrt_sqrtf(1.0f + alpha * alpha * (1.0f - ndv2) / ndv2) - 1.0f) / 2.0f;
+}
+RT_DEV float g1_ggx(float ndv, float alpha) { return 1.0f / (1.0f + lambda_ggx(ndv, alpha)); } // :1026-1028
+RT_DEV V3 f_schlick(V3 f0, float c) // :1045-1051
+{
+    float x = 1.0f - saturate(c);
+    float x2 = x * x;
+    float x5 = x2 * x2 * x;
+    return f0 + (v3(1, 1, 1) - f0) * x5;
+}
+RT_DEV V3 bsdf_eval_local(V3 wo, V3 wi, const BsdfMaterial &m) // :1053-1087
+{
+    if (wo.z <= 0.0f || wi.z <= 0.0f) return v3(0, 0, 0);
+    V3 h = normalize(wo + wi);
+    float ndh = saturate(h.z);
+    float D = d_ggx(ndh, m.alpha);
+    float G = g1_ggx(wo.z, m.alpha) * g1_ggx(wi.z, m.alpha);
+    V3 F = f_schlick(m.f0, dot(h, wo));
+    V3 fs = (D * G) / (4.0f * wo.z * wi.z) * F;
+    V3 fd = m.kd * RT_INV_PI;
+    return fd + fs;
+}
+RT_DEV float bsdf_pdf_local(V3 wo, V3 wi, const BsdfMaterial &m) // :1104-1114 with :1089-1102, :931-945, :914-919
+{
+    if (wo.z <= 0.0f || wi.z <= 0.0f) return 0.0f;
+    float pdf_cos = wi.z / RT_PI; // wi.z > 0 here
+    float pdf_spec;
+    {
+        V3 h = normalize(wo + wi);
+        float wo_dot_h = fabs_(dot(wo, h));
+        if (wo_dot_h <= 0.0f) pdf_spec = 0.0f;
+        else {
+            float hv;
+            if (h.z <= 0.0f) hv = 0.0f;
+            else hv = d_ggx(h.z, m.alpha) * g1_ggx(wo.z, m.alpha) * fmax_(0.0f, dot(wo, h)) / wo.z;
+            pdf_spec = hv / (4.0f * wo_dot_h);
+        }
+    }
+    return m.diff_prob * pdf_cos + m.spec_prob * pdf_spec;
+}
+RT_DEV V3 sample_cosine_hemisphere(float sx, float sy) // :892-901
+{
+    float r = rsrt_sqrtf(sx);
+    float phi = RT_TWO_PI * sy;
+    float x = r * rsrt_cosf(phi), y = r * rsrt_sinf(phi);
+    float z = rsrt_sqrtf(fmax_(0.0f, 1.0f - x * x - y * y));
+    return v3(x, y, z);
+}
+RT_DEV V3 sample_ggx_visible_half_vector(float sx, float sy, V3 wo, float alpha) // :962-1009
+{
+    V3 vs = normalize(wo * v3(alpha, alpha, 1.0f));
+    float len2 = dot2(vs.x, vs.y, vs.x, vs.y);
+    V3 alt = v3(-vs.y, vs.x, 0.0f) * inverse_sqrt(len2);
+    V3 tx = (len2 > 0.0f) ? alt : v3(1, 0, 0);
+    V3 ty = cross(vs, tx);
+    float radius = rsrt_sqrtf(sx);
+    float az = RT_TWO_PI * sy;
+    float dx = radius * rsrt_cosf(az), dy = radius * rsrt_sinf(az);
+    float a = rsrt_sqrtf(fmax_(0.0f, 1.0f - dx * dx));
+    dy = (1.0f - vs.z) * a + vs.z * dy; // lerp_f32(a, dy, vs.z)
+    V3 hs = dx * tx + dy * ty + rsrt_sqrtf(fmax_(0.0f, 1.0f - dx * dx - dy * dy)) * vs;
+    return normalize(v3(alpha * hs.x, alpha * hs.y, fmax_(0.0f, hs.z)));
+}
+struct BsdfSample {
+    V3 dir, scattering;
+    float pdf;
+};
+RT_DEV BsdfSample bsdf_sample(V3 ray_dir, V3 n, const BsdfMaterial &m, uint32_t &rng) // :1116-1202
+{
+    V3 wo_world = -ray_dir;
+    if (dot(n, wo_world) <= 0.0f) return BsdfSample{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
+    Frame frame = make_frame(n);
+    V3 wo = to_frame_local(frame, wo_world);
+    if (wo.z <= 0.0f) return BsdfSample{v3(0, 0, 0), v3(0, 1, 0), 0.0f};
+    V3 wi;
+    float s = random_uniform(rng);
+    if (s < m.diff_prob) {
+        float s0 = s / fmax_(m.diff_prob, 1.e-6f);
+        float s1 = random_uniform(rng);
+        wi = sample_cosine_hemisphere(s0, s1);
+    } else {
+        float s0 = (s - m.diff_prob) / fmax_(m.spec_prob, 1.e-6f);
+        float s1 = random_uniform(rng);
+        V3 h = sample_ggx_visible_half_vector(s0, s1, wo, m.alpha);
+        V3 i = -wo;
+        wi = i - (2.0f * dot(h, i)) * h; // reflect(-wo, h)
+        if (wi.z <= 0.0f) return BsdfSample{v3(1, 0, 0), v3(1, 0, 0), 0.0f};
+    }
+    V3 scattering = bsdf_eval_local(wo, wi, m);
+    float pdf = bsdf_pdf_local(wo, wi, m);
+    V3 wi_world = to_frame_world(frame, wi);
+    if (dot(n, wi_world) < 0.0f) return BsdfSample{v3(0, 0, 0), v3(0, 1, 0), 0.0f};
+    return BsdfSample{wi_world, scattering, pdf};
+}
+RT_DEV float power_heuristic(float a, float b) // :1206-1210
+{
+    float a2 = a * a, b2 = b * b;
+    return a2 / (a2 + b2);
+}

@@ -1,0 +1,66 @@
+// rt_math.h — f32 vector helpers for the gfx950 kernels.
+//
+// Arithmetic contract (identical on the CPU checker side, see DESIGN.md "Numerics"):
+//  * compiled with -ffp-contract=off: each written * + - / sqrt is ONE correctly rounded IEEE
+//    binary32 operation (hipcc: -fhip-fp32-correctly-rounded-divide-sqrt, denormals kept);
+//  * the only fused multiply-adds are the explicit fmaf() calls in dot / dot2 / cross /
+//    mat3_mul / madd below;
+//  * normalize(v) = v * (1/sqrt(dot(v,v))), inverse_sqrt(x) = 1/sqrt(x), length = sqrt(dot);
+//  * fmax_/fmin_ are the compare-select forms (a<b?b:a / b<a?b:a), NaN handling included;
+//  * transcendental functions come from include/rsrt_detmath.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../../include/rsrt_detmath.h"
+
+#define RT_DEV __device__ __forceinline__
+
+struct V3 {
+    float x, y, z;
+};
+RT_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+RT_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_DEV V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT_DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+RT_DEV V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+RT_DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+RT_DEV V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+RT_DEV float comp(V3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+RT_DEV float fmax_(float a, float b) { return a < b ? b : a; }
+RT_DEV float fmin_(float a, float b) { return b < a ? b : a; }
+RT_DEV float saturate(float x) { return fmin_(fmax_(x, 0.0f), 1.0f); }
+RT_DEV float fabs_(float x) { return __builtin_fabsf(x); }
+
+RT_DEV float dot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+RT_DEV float dot2(float ax, float ay, float bx, float by) { return __builtin_fmaf(ay, by, ax * bx); }
+RT_DEV V3 cross(V3 a, V3 b)
+{
+    return V3{__builtin_fmaf(a.y, b.z, -(b.y * a.z)), __builtin_fmaf(a.z, b.x, -(b.z * a.x)),
+              __builtin_fmaf(a.x, b.y, -(b.x * a.y))};
+}
+// o + d*t
+RT_DEV V3 madd(V3 d, float t, V3 o) { return V3{__builtin_fmaf(d.x, t, o.x), __builtin_fmaf(d.y, t, o.y), __builtin_fmaf(d.z, t, o.z)}; }
+// column-major 3x3 times vector
+RT_DEV V3 mat3_mul(V3 c0, V3 c1, V3 c2, V3 v)
+{
+    return V3{__builtin_fmaf(c2.x, v.z, __builtin_fmaf(c1.x, v.y, c0.x * v.x)),
+              __builtin_fmaf(c2.y, v.z, __builtin_fmaf(c1.y, v.y, c0.y * v.x)),
+              __builtin_fmaf(c2.z, v.z, __builtin_fmaf(c1.z, v.y, c0.z * v.x))};
+}
+RT_DEV float length(V3 a) { return rsrt_sqrtf(dot(a, a)); }
+RT_DEV V3 normalize(V3 a) { return a * (1.0f / rsrt_sqrtf(dot(a, a))); }
+RT_DEV float inverse_sqrt(float x) { return 1.0f / rsrt_sqrtf(x); }
+
+// WGSL u32(f32) as naga emits it: NaN / negative -> 0, clamp at the largest f32 below 2^32
+RT_DEV uint32_t f2u(float x)
+{
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 4294967040.0f) return 4294967040u;
+    return (uint32_t)x;
+}
+
+RT_DEV float as_f(uint32_t u) { return __uint_as_float(u); }
+RT_DEV uint32_t as_u(float f) { return __float_as_uint(f); }

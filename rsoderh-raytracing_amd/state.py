@@ -1,0 +1,220 @@
+"""`State` — the host render state of the reference (src/state.rs:29-834) over librsrt.so.
+
+    State.new(scene, environments)   State::new   (state.rs:60-649): uploads the eight scene
+                                     buffers and the environment maps + alias tables
+    state.resize(w, h)               State::resize (state.rs:651-666): accumulator follows the size
+    state.update(camera=..)          State::update (state.rs:722-758): per-frame uniforms
+    state.render()                   State::render (state.rs:760-833): one progressive frame —
+                                     scene-hash reset, sample_count += 1, one dispatch
+    state.render_samples(n)          the batched form the C-ABI adds: n samples in one call
+
+No CPU fallback: constructing a State without librsrt.so / a gfx950 GPU raises RsrtError.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _build, types as T
+
+FLAG_REFERENCE_TRAVERSAL = 1
+
+_SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "rsrt_upload_scene",
+            "rsrt_upload_environment", "rsrt_set_partition", "rsrt_accumulator_resize", "rsrt_accumulator_bind",
+            "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_render",
+            "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe"]
+
+
+class RsrtError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("ext_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("kernel_ms", C.c_double),
+                ("total_paths", C.c_uint64), ("total_ext_rays", C.c_uint64), ("total_shadow_rays", C.c_uint64),
+                ("total_kernel_ms", C.c_double), ("launches", C.c_uint32), ("_pad", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "_pad"}
+
+
+_lib = None
+
+
+def lib():
+    """Loads librsrt.so (building it in-tree when sources are newer). Raises if it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        try:
+            path = _build.build_hip()
+            L = C.CDLL(path)
+        except Exception as e:  # noqa: BLE001
+            raise RsrtError("librsrt.so (the HIP integrator) is not available: %s" % e) from e
+        for s in _SYMBOLS:
+            getattr(L, s)
+        L.rsrt_last_error.restype = C.c_char_p
+        L.rsrt_last_error.argtypes = [C.c_void_p]
+        L.rsrt_describe.restype = C.c_char_p
+        L.rsrt_describe.argtypes = [C.c_void_p]
+        L.rsrt_context_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.rsrt_context_destroy.argtypes = [C.c_void_p]
+        L.rsrt_upload_scene.argtypes = [C.c_void_p] + [C.c_void_p, C.c_uint32] * 8
+        L.rsrt_upload_environment.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rsrt_set_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.rsrt_accumulator_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.rsrt_accumulator_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.rsrt_accumulator_clear.argtypes = [C.c_void_p]
+        L.rsrt_accumulator_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.rsrt_resolve_mean_f16.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+        L.rsrt_render.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p]
+        L.rsrt_synchronize.argtypes = [C.c_void_p]
+        L.rsrt_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.rsrt_cast_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class State:
+    def __init__(self, device=0):
+        self._L = lib()
+        self._ctx = C.c_void_p()
+        rc = self._L.rsrt_context_create(device, C.byref(self._ctx))
+        if rc != 0:
+            raise RsrtError("rsrt_context_create: %s" % self._L.rsrt_last_error(None).decode())
+        self.width = self.height = 0
+        self.sample_count = 0          # hdr.sample_count (state.rs:775-789)
+        self.max_bounces = 10          # MAX_BOUNCES (shader.wgsl:232)
+        self.environment_index = 0     # state.rs:638
+        self.camera = None
+        self._last_hash = None
+        self.flags = 0
+
+    # -- construction ---------------------------------------------------------------------------
+    @classmethod
+    def new(cls, scene, environments, width, height, device=0, camera=None):
+        st = cls(device)
+        st.upload_scene(scene)
+        for i, env in enumerate(environments if isinstance(environments, (list, tuple)) else [environments]):
+            st.upload_environment(i, env)
+        st.resize(width, height)
+        st.camera = np.array(camera if camera is not None else scene.camera_uniform()).view(T.CAMERA).reshape(1).copy()
+        return st
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RsrtError("%s failed (%d): %s" % (what, rc, self._L.rsrt_last_error(self._ctx).decode()))
+
+    def close(self):
+        if self._ctx:
+            self._L.rsrt_context_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def describe(self):
+        return self._L.rsrt_describe(self._ctx).decode()
+
+    def upload_scene(self, scene):
+        a = [scene.materials, scene.spheres, scene.planes, scene.vertices, scene.normals, scene.triangles, scene.primitives,
+             scene.bvh_nodes]
+        dts = [T.MATERIAL, T.SPHERE, T.PLANE, T.VEC3, T.VEC3, T.TRIANGLE, T.PRIMITIVE_INFO, T.BVH_NODE]
+        args = []
+        for arr, dt in zip(a, dts):
+            arr = np.ascontiguousarray(arr)
+            assert arr.dtype.itemsize == dt.itemsize, (arr.dtype, dt)
+            args += [_p(arr), len(arr)]
+        self._keep = a
+        self._check(self._L.rsrt_upload_scene(self._ctx, *args), "rsrt_upload_scene")
+
+    def upload_environment(self, slot, env):
+        rgba = np.ascontiguousarray(env.rgba, dtype=np.float32)
+        alias = np.ascontiguousarray(env.alias)
+        assert rgba.shape == (env.height, env.width, 4) and alias.dtype.itemsize == 16 and len(alias) == env.width * env.height
+        self._check(self._L.rsrt_upload_environment(self._ctx, slot, env.width, env.height, _p(rgba), _p(alias)),
+                    "rsrt_upload_environment")
+
+    def set_partition(self, rank, world_size, tile_w=16, tile_h=16):
+        self._check(self._L.rsrt_set_partition(self._ctx, rank, world_size, tile_w, tile_h), "rsrt_set_partition")
+
+    # -- State::resize / update / render --------------------------------------------------------
+    def resize(self, width, height):
+        self._check(self._L.rsrt_accumulator_resize(self._ctx, width, height), "rsrt_accumulator_resize")
+        self.width, self.height = width, height
+        self._last_hash = None
+
+    def bind_accumulator(self, device_ptr, width, height):
+        """Use caller-owned device memory (W*H*4 f32), e.g. a torch tensor's data_ptr()."""
+        self._check(self._L.rsrt_accumulator_bind(self._ctx, C.c_void_p(device_ptr), width, height), "rsrt_accumulator_bind")
+        self.width, self.height = width, height
+        self._last_hash = None
+
+    def update(self, camera=None, environment_index=None):
+        if camera is not None:
+            self.camera = np.array(camera).view(T.CAMERA).reshape(1).copy()
+        if environment_index is not None:
+            self.environment_index = environment_index
+
+    def _scene_hash(self):
+        return hash((self.camera.tobytes(), self.environment_index))
+
+    def clear(self):
+        self._check(self._L.rsrt_accumulator_clear(self._ctx), "rsrt_accumulator_clear")
+        self.sample_count = 0
+
+    def render_samples(self, n, stream=None):
+        """Adds samples [sample_count, sample_count+n); resets first when camera/environment changed."""
+        h = self._scene_hash()
+        if h != self._last_hash:  # state.rs:778-786
+            self._last_hash = h
+            self.clear()
+        self._check(self._L.rsrt_render(self._ctx, _p(self.camera), self.width, self.height, self.sample_count, n,
+                                        self.max_bounces, self.environment_index, self.flags,
+                                        C.c_void_p(stream) if stream else None), "rsrt_render")
+        self.sample_count += n
+
+    def render(self):
+        """One reference frame: exactly one more sample per pixel."""
+        self.render_samples(1)
+
+    def render_range(self, sample_begin, sample_count, stream=None):
+        """Raw rsrt_render: no hash check, no counter update."""
+        self._check(self._L.rsrt_render(self._ctx, _p(self.camera), self.width, self.height, sample_begin, sample_count,
+                                        self.max_bounces, self.environment_index, self.flags,
+                                        C.c_void_p(stream) if stream else None), "rsrt_render")
+
+    def synchronize(self):
+        self._check(self._L.rsrt_synchronize(self._ctx), "rsrt_synchronize")
+
+    # -- results ---------------------------------------------------------------------------------
+    def download(self):
+        """cumulative_light_texture: [H, W, 4] float32 sums, alpha 1 where rendered."""
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._L.rsrt_accumulator_download(self._ctx, _p(out), out.size), "rsrt_accumulator_download")
+        return out
+
+    def download_mean_f16(self, sample_total=None):
+        """out_texture: [H, W, 4] float16 mean radiance."""
+        out = np.empty((self.height, self.width, 4), np.float16)
+        n = sample_total if sample_total is not None else self.sample_count
+        self._check(self._L.rsrt_resolve_mean_f16(self._ctx, n, _p(out), out.size), "rsrt_resolve_mean_f16")
+        return out
+
+    def stats(self):
+        s = Stats()
+        self._check(self._L.rsrt_get_stats(self._ctx, C.byref(s)), "rsrt_get_stats")
+        return s.as_dict()
+
+    def cast_rays(self, origins, directions, mode=0, flags=0):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        assert o.shape == d.shape
+        out = np.zeros(len(o), T.HIT)
+        self._check(self._L.rsrt_cast_rays(self._ctx, len(o), _p(o), _p(d), mode, flags, _p(out)), "rsrt_cast_rays")
+        return out
