@@ -58,7 +58,8 @@ enum {
     RSRT_FLAG_REFERENCE_TRAVERSAL = 1u
 };
 
-/* Counters of the last rsrt_render call (and cumulative since context creation). */
+/* Counters of the work submitted since the previous rsrt_get_stats call (and cumulative since
+ * context creation).  Times are HIP-event times on the stream the kernels were launched on. */
 typedef struct rsrt_stats {
     uint64_t paths;        /* camera paths started */
     uint64_t ext_rays;     /* calls of cast_ray (shader.wgsl:1221) */
@@ -66,8 +67,10 @@ typedef struct rsrt_stats {
     double kernel_ms;      /* HIP-event time of the integrator kernel(s) on the launch stream */
     uint64_t total_paths, total_ext_rays, total_shadow_rays;
     double total_kernel_ms;
-    uint32_t launches;     /* kernel launches of the last call */
+    uint32_t launches;     /* kernel launches since the previous rsrt_get_stats */
     uint32_t _pad;
+    double trace_kernel_ms;   /* part of kernel_ms spent in the path-tracing kernel (rt_render_kernel) */
+    double resolve_kernel_ms; /* part spent in the ordered sample resolve (rt_resolve_kernel) */
 } rsrt_stats;
 
 /* -- context: State::new's device acquisition (state.rs:60-98) ------------------------------ */

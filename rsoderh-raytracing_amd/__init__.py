@@ -7,15 +7,9 @@ State/Scene surface.
 
 There is no CPU fallback: `State` raises if librsrt.so or a GPU is missing.
 """
-from . import types  # noqa: F401
+from . import state, types  # noqa: F401
 from .host import AliasTable, Environment, Scene, SceneError, build_bvh, camera_uniform, plane_to_uniform  # noqa: F401
 
 __all__ = ["types", "Scene", "SceneError", "Environment", "AliasTable", "build_bvh", "camera_uniform",
            "plane_to_uniform", "State"]
-
-
-def __getattr__(name):
-    if name == "State":
-        from .state import State
-        return State
-    raise AttributeError(name)
+from .state import RsrtError, State  # noqa: E402,F401  (librsrt.so itself is loaded on first use)

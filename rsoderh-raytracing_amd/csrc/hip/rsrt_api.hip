@@ -304,6 +304,8 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
         r.hit_point[0] = s.point.x; r.hit_point[1] = s.point.y; r.hit_point[2] = s.point.z;
         r.normal[0] = s.normal.x; r.normal[1] = s.normal.y; r.normal[2] = s.normal.z;
         r.material_id = s.material_id;
+    } else if (mode == 0) {
+        r.distance = RT_INFINITY; // cast_ray returns its `result` initialiser on a total miss (shader.wgsl:568-574, :600)
     }
     out[i] = r;
 }
@@ -358,7 +360,9 @@ struct rsrt_context {
     // stats
     rsrt_stats stats{};
     bool stats_pending = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    struct PassEvents { hipEvent_t begin, traced, end; };
+    std::vector<PassEvents> pending_events;
+    double trace_ms_acc = 0, resolve_ms_acc = 0;
     std::vector<hipEvent_t> event_pool;
     int blocks_per_cu_lds = 0, blocks_per_cu_glb = 0;
     uint32_t launches_pending = 0;
@@ -465,16 +469,22 @@ rsrt_status collect_stats(rsrt_context *ctx)
 {
     if (!ctx->stats_pending) return RSRT_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    double ms = 0;
-    for (auto &pr : ctx->pending_events) {
-        float t = 0;
-        HIP_TRY(ctx, hipEventSynchronize(pr.second));
-        HIP_TRY(ctx, hipEventElapsedTime(&t, pr.first, pr.second));
-        ms += t;
-        ctx->event_pool.push_back(pr.first);
-        ctx->event_pool.push_back(pr.second);
+    double ms = 0, trace_ms = 0, resolve_ms = 0;
+    for (auto &pe : ctx->pending_events) {
+        float t1 = 0, t2 = 0;
+        HIP_TRY(ctx, hipEventSynchronize(pe.end));
+        HIP_TRY(ctx, hipEventElapsedTime(&t1, pe.begin, pe.traced));
+        HIP_TRY(ctx, hipEventElapsedTime(&t2, pe.traced, pe.end));
+        trace_ms += t1;
+        resolve_ms += t2;
+        ms += t1 + t2;
+        ctx->event_pool.push_back(pe.begin);
+        ctx->event_pool.push_back(pe.traced);
+        ctx->event_pool.push_back(pe.end);
     }
     ctx->pending_events.clear();
+    ctx->stats.trace_kernel_ms = trace_ms;
+    ctx->stats.resolve_kernel_ms = resolve_ms;
     unsigned long long c[3] = {0, 0, 0}; // device counters are cumulative
     HIP_TRY(ctx, hipMemcpy(c, ctx->dev_stats, sizeof c, hipMemcpyDeviceToHost));
     ctx->stats.paths = c[0] - ctx->stats.total_paths;
@@ -535,7 +545,7 @@ void rsrt_context_destroy(rsrt_context *ctx)
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &pr : ctx->pending_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &pe : ctx->pending_events) { (void)hipEventDestroy(pe.begin); (void)hipEventDestroy(pe.traced); (void)hipEventDestroy(pe.end); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->scene_blob);
     for (auto &e : ctx->envs) { (void)hipFree(e.rgba); (void)hipFree(e.alias); }
@@ -775,7 +785,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
     rsrt_status st = ensure_accumulator(ctx, width, height);
     if (st) return st;
-    if (ctx->pending_events.size() >= 64) { st = collect_stats(ctx); if (st) return st; } // bounds the event pool
+    if (ctx->pending_events.size() >= 32) { st = collect_stats(ctx); if (st) return st; } // bounds the event pool
     if (sample_count == 0) return RSRT_OK;
 
     RenderParams P;
@@ -826,9 +836,10 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         bpc = std::min(nb, 8);
     }
 
-    hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
-    HIP_TRY(ctx, hipEventRecord(e0, stream));
+    hipEvent_t last_end = nullptr;
     for (uint32_t done = 0; done < sample_count; done += pass_samples) {
+        rsrt_context::PassEvents pe = {get_event(ctx), get_event(ctx), get_event(ctx)};
+        HIP_TRY(ctx, hipEventRecord(pe.begin, stream));
         P.sample_begin = sample_begin + done;
         P.sample_count = std::min(pass_samples, sample_count - done);
         if (max_bounces > 0) {
@@ -849,16 +860,18 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         } else {
             HIP_TRY(ctx, hipMemsetAsync(ctx->sample_buf, 0, per_sample * P.sample_count, stream));
         }
+        HIP_TRY(ctx, hipEventRecord(pe.traced, stream));
         hipLaunchKernelGGL(rt_resolve_kernel, dim3((P.n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, P, ctx->accum);
         HIP_TRY(ctx, hipGetLastError());
         ctx->launches_pending++;
+        HIP_TRY(ctx, hipEventRecord(pe.end, stream));
+        ctx->pending_events.push_back(pe);
+        ctx->stats_pending = true;
+        last_end = pe.end;
     }
-    HIP_TRY(ctx, hipEventRecord(e1, stream));
-    ctx->pending_events.push_back({e0, e1});
-    ctx->stats_pending = true;
-    if (stream != ctx->stream) {
+    if (stream != ctx->stream && last_end) {
         // keep the context's own stream ordered after work submitted on the caller's stream
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e1, 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, last_end, 0));
     }
     return RSRT_OK;
 }

@@ -1,0 +1,200 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle and the committed
+golden vectors.  Integer/index work and — because both sides evaluate the same correctly-rounded
+f32 expression trees (DESIGN.md "Numerics") — the radiance sums too are compared BIT-EXACT; the
+north-star tolerance (1e-3 per-channel RMSE) is asserted as well where stated."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import util
+import rsoderh_raytracing_amd as R
+from rsoderh_raytracing_amd import partition
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["house", "default", "cube", "suzanne", "spheres_only"]
+RMSE_TOL = 1e-3  # BASELINE.json north_star
+
+
+def golden(name):
+    return np.load(os.path.join(util.ROOT, "tests", "golden", "scene_%s.npz" % name))
+
+
+def golden_env():
+    g = np.load(os.path.join(util.ROOT, "tests", "golden", "env_64x32.npz"))
+    return R.Environment(g["rgba"], g["alias"].view(R.types.ALIAS_ENTRY).reshape(-1))
+
+
+@pytest.fixture(scope="module")
+def big_env():
+    return R.Environment.synthetic(2048, 1024)
+
+
+def gpu_render(scene, env, w, h, begin, count, mb, flags=0, partition_args=None):
+    st = R.State.new(scene, env, w, h)
+    st.max_bounces, st.flags = mb, flags
+    if partition_args:
+        st.set_partition(*partition_args)
+    st.render_range(begin, count)
+    img, stats = st.download(), st.stats()
+    st.close()
+    return img, stats
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_matches_golden_images_bit_exact(name):
+    g = golden(name)
+    sc, env = R.Scene.load_toml(util.scene_path(name)), golden_env()
+    for key in [k for k in g.files if k.startswith("sum_")]:
+        spp, mb = int(key.split("_")[1][:-3]), int(key.split("_")[2][:-1])
+        for flags in (0, R.state.FLAG_REFERENCE_TRAVERSAL):
+            img, st = gpu_render(sc, env, 64, 64, 0, spp, mb, flags)
+            assert np.array_equal(util.bits(img), util.bits(g[key])), (key, flags)
+            assert [st["paths"], st["ext_rays"], st["shadow_rays"]] == list(g["rays_%dspp_%db" % (spp, mb)])
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_ray_batch_matches_golden_bit_exact(name):
+    g = golden(name)
+    st = R.State.new(R.Scene.load_toml(util.scene_path(name)), golden_env(), 16, 16)
+    for mode, key in [(0, "hits"), (1, "hits_bvh")]:
+        for flags in (0, R.state.FLAG_REFERENCE_TRAVERSAL):
+            h = st.cast_rays(g["ray_o"], g["ray_d"], mode, flags)
+            assert np.array_equal(np.ascontiguousarray(h).view(np.uint32).reshape(-1, 9), g[key]), (key, flags)
+    st.close()
+
+
+@pytest.mark.parametrize("name,w,h,spp,mb", [("house", 160, 90, 8, 8), ("default", 128, 72, 8, 10), ("suzanne", 96, 64, 4, 10),
+                                             ("house", 67, 35, 3, 10), ("cube", 128, 72, 8, 10)])
+def test_matches_oracle_live(name, w, h, spp, mb, big_env):
+    """Seeded live comparison on the full-size 2048x1024 environment (ragged sizes included)."""
+    sc = R.Scene.load_toml(util.scene_path(name))
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), w, h, 0, spp, mb)
+    img, st = gpu_render(sc, big_env, w, h, 0, spp, mb)
+    assert np.all(util.rmse_per_channel(img, ref, spp) <= RMSE_TOL)
+    assert np.array_equal(util.bits(img), util.bits(ref))
+    assert (st["paths"], st["ext_rays"], st["shadow_rays"]) == (ost["paths"], ost["ext_rays"], ost["shadow_rays"])
+
+
+def test_sample_ranges_compose_exactly(big_env):
+    """[0,5) then [5,12) into the same accumulator == [0,12) in one call, and == 12 reference frames."""
+    sc = R.Scene.load_toml(util.scene_path("house"))
+    one, _ = gpu_render(sc, big_env, 96, 54, 0, 12, 8)
+    st = R.State.new(sc, big_env, 96, 54)
+    st.max_bounces = 8
+    st.render_range(0, 5)
+    st.render_range(5, 7)
+    two = st.download()
+    st.clear()
+    for _ in range(12):
+        st._last_hash = st._scene_hash()
+        st.render()  # State::render: one sample per frame
+    prog = st.download()
+    st.close()
+    assert np.array_equal(util.bits(one), util.bits(two))
+    assert np.array_equal(util.bits(one), util.bits(prog))
+
+
+def test_sample_buffer_passes_do_not_change_the_image(big_env, monkeypatch):
+    sc = R.Scene.load_toml(util.scene_path("default"))
+    a, _ = gpu_render(sc, big_env, 320, 192, 0, 5, 6)
+    monkeypatch.setenv("RSRT_SAMPLE_BUFFER_MB", "1")  # 0.74 MB per sample -> one pass per sample
+    b, st = gpu_render(sc, big_env, 320, 192, 0, 5, 6)
+    assert st["launches"] > 2
+    assert np.array_equal(util.bits(a), util.bits(b))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_tile_partition_union_is_the_full_image(world, big_env):
+    """Each 'rank' renders only its tiles; the sum over ranks (what the RCCL reduce computes) is
+    bit-identical to the single-GPU image, and no rank touches a pixel it does not own."""
+    sc = R.Scene.load_toml(util.scene_path("house"))
+    w, h = 200, 120
+    full, fst = gpu_render(sc, big_env, w, h, 0, 4, 8)
+    total = np.zeros_like(full)
+    rays = 0
+    for r in range(world):
+        part, st = gpu_render(sc, big_env, w, h, 0, 4, 8, partition_args=(r, world, 16, 16))
+        m = partition.owned_mask(w, h, r, world)
+        assert np.all(part[~m] == 0)
+        total += part
+        rays += st["ext_rays"] + st["shadow_rays"]
+    assert np.array_equal(util.bits(total), util.bits(full))
+    assert rays == fst["ext_rays"] + fst["shadow_rays"]
+
+
+def test_full_size_properties(big_env):
+    """BASELINE config 4 geometry (1920x1080, 8 bounces) at 2 spp: linear in samples, alpha 1,
+    finite, and the oracle agrees on a sampled window of rows."""
+    sc = R.Scene.load_toml(util.scene_path("house"))
+    st = R.State.new(sc, big_env, 1920, 1080)
+    st.max_bounces = 8
+    st.render_range(0, 2)
+    a = st.download()
+    s = st.stats()
+    st.close()
+    assert np.isfinite(a).all() and np.all(a[..., 3] == 1.0) and a[..., :3].min() >= 0
+    assert s["paths"] == 1920 * 1080 * 2 and s["ext_rays"] >= s["paths"]
+    ref, _ = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 1920, 1080, 0, 2, 8)
+    assert np.array_equal(util.bits(a), util.bits(ref))
+
+
+def test_mean_f16_and_alpha(big_env):
+    sc = R.Scene.load_toml(util.scene_path("default"))
+    st = R.State.new(sc, big_env, 64, 40)
+    st.render_samples(3)
+    s, m = st.download(), st.download_mean_f16()
+    st.close()
+    assert np.array_equal(m[..., :3], (s[..., :3] / np.float32(3)).astype(np.float16))
+    assert np.all(m[..., 3] == 1.0)
+
+
+def test_scene_hash_reset_and_environment_switch(big_env):
+    sc = R.Scene.load_toml(util.scene_path("default"))
+    st = R.State.new(sc, [big_env, golden_env()], 48, 32)
+    st.render_samples(2)
+    assert st.sample_count == 2
+    st.update(environment_index=1)
+    st.render()  # scene hash changed -> accumulator cleared, sample index restarts at 0
+    assert st.sample_count == 1
+    a = st.download()
+    st.close()
+    ref, _ = oracle.render(util.oracle_scene(sc), util.oracle_env(golden_env()), sc.camera_uniform().view(oracle.CAMERA), 48, 32, 0, 1, 10)
+    assert np.array_equal(util.bits(a), util.bits(ref))
+
+
+def test_zero_bounces_and_zero_samples(big_env):
+    sc = R.Scene.load_toml(util.scene_path("default"))
+    st = R.State.new(sc, big_env, 32, 16)
+    st.max_bounces = 0
+    st.render_range(0, 3)
+    a = st.download()
+    assert np.all(a[..., :3] == 0) and np.all(a[..., 3] == 1)
+    st.render_range(3, 0)
+    st.close()
+
+
+def test_invalid_input_is_rejected_not_launched(big_env):
+    from rsoderh_raytracing_amd.state import RsrtError
+    sc = R.Scene.load_toml(util.scene_path("default"))
+    st = R.State(0)
+    with pytest.raises(RsrtError, match="no scene"):
+        st.camera = sc.camera_uniform()
+        st.width, st.height = 8, 8
+        st.render_range(0, 1)
+    bad = R.Scene.load_toml(util.scene_path("default"))
+    bad.triangles = bad.triangles.copy()
+    bad.triangles["vertex_0"][0] = 10 ** 6
+    with pytest.raises(RsrtError, match="vertex index out of range"):
+        st.upload_scene(bad)
+    bad = R.Scene.load_toml(util.scene_path("default"))
+    bad.bvh_nodes = bad.bvh_nodes.copy()
+    bad.bvh_nodes["primitives_or_second_child_index"][0] = 0  # cycle
+    with pytest.raises(RsrtError, match="bvh"):
+        st.upload_scene(bad)
+    st.upload_scene(sc)
+    with pytest.raises(RsrtError, match="environment 0 not uploaded"):
+        st.render_range(0, 1)
+    st.close()

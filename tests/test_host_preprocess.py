@@ -1,0 +1,135 @@
+"""Product host library (librsrt_host.so, C++) against the oracle's independent restatement and
+against an independent Python scene reader: every array must be bit-identical."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import util
+from oracle import scene_py
+import rsoderh_raytracing_amd as R
+from rsoderh_raytracing_amd import host, types as T
+
+SCENES = ["house", "default", "cube", "suzanne", "spheres_only"]
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_scene_loader_matches_python_reader_and_oracle_bvh(name):
+    s = R.Scene.load_toml(util.scene_path(name))
+    o = scene_py.load_toml(util.scene_path(name))
+    sc = o["scene"]
+    for a, b in [(sc.materials, s.materials), (sc.spheres, s.spheres), (sc.planes, s.planes), (sc.vertices, s.vertices),
+                 (sc.normals, s.normals), (sc.triangles, s.triangles), (sc.prims, s.primitives), (sc.nodes, s.bvh_nodes)]:
+        assert util.fields_equal(a, b)
+    assert o["depth"] == s.bvh_depth
+    assert util.fields_equal(o["camera"], s.camera_uniform())
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_bvh_matches_golden(name):
+    g = np.load(os.path.join(util.ROOT, "tests", "golden", "scene_%s.npz" % name))
+    s = R.Scene.load_toml(util.scene_path(name))
+    assert np.array_equal(s.primitives.view(np.uint32).reshape(-1, 2), g["bvh_prims"])
+    got = np.ascontiguousarray(s.bvh_nodes).view(np.uint32).reshape(-1, 12)
+    keep = [0, 1, 2, 4, 5, 6, 8, 9, 10]  # skip padding words
+    assert np.array_equal(got[:, keep], g["bvh_nodes"][:, keep])
+    assert s.bvh_depth == int(g["depth"])
+
+
+def test_bvh_random_scenes_match_oracle():
+    rng = np.random.default_rng(7)
+    for trial in range(25):
+        ns, npl, nt = rng.integers(0, 12), rng.integers(0, 4), rng.integers(0, 60)
+        if ns + npl + nt == 0:
+            ns = 1
+        sph = np.zeros(ns, T.SPHERE)
+        sph["pos"] = rng.uniform(-5, 5, (ns, 3))
+        sph["radius"] = rng.uniform(0.05, 1.5, ns)
+        pls = np.zeros(npl, T.PLANE_DESC)
+        pls["pos"] = rng.uniform(-5, 5, (npl, 3))
+        pls["forward"] = rng.uniform(-3, 3, (npl, 3))
+        pls["right"] = rng.uniform(-3, 3, (npl, 3))
+        verts = np.zeros(max(3, nt), T.VEC3)
+        # a coarse grid makes equal centroids / degenerate splits likely
+        verts["v"] = np.round(rng.uniform(-4, 4, (len(verts), 3)) * (2 if trial % 2 else 64)) / (2 if trial % 2 else 64)
+        tri = np.zeros(nt, T.TRIANGLE)
+        for k in ("vertex_0", "vertex_1", "vertex_2"):
+            tri[k] = rng.integers(0, len(verts), nt)
+        p1, n1, d1 = host.build_bvh(sph, pls, verts, tri)
+        p2, n2, d2 = oracle.build_bvh(sph.view(oracle.SPHERE), pls.view(oracle.PLANE_SRC), verts.view(oracle.VEC3),
+                                      tri.view(oracle.TRIANGLE))
+        assert util.fields_equal(p1, p2) and util.fields_equal(n1, n2) and d1 == d2
+
+
+def test_empty_scene_is_an_error():
+    with pytest.raises(ValueError):
+        host.build_bvh(np.zeros(0, T.SPHERE), np.zeros(0, T.PLANE_DESC), np.zeros(0, T.VEC3), np.zeros(0, T.TRIANGLE))
+
+
+def test_alias_table_matches_oracle_and_golden():
+    g = np.load(os.path.join(util.ROOT, "tests", "golden", "alias_8x4.npz"))
+    env = R.Environment.synthetic(8, 4)
+    assert np.array_equal(util.bits(env.rgba), util.bits(g["rgba"]))  # frozen synthetic-sky formula
+    assert np.array_equal(env.alias.view(np.uint32).reshape(-1, 4), g["alias"]) and env.leftover == int(g["leftover"])
+    rng = np.random.default_rng(3)
+    for w, h in [(1, 1), (2, 1), (4, 1), (7, 5), (64, 32), (31, 17)]:
+        rgb = (rng.uniform(0, 1, (h, w, 3)) ** 6 * 100).astype(np.float32)
+        a, la = R.AliasTable.build_by_luminance(rgb)
+        b, lb = oracle.alias_table(rgb)
+        assert util.fields_equal(a, b) and la == lb
+        # every alias index in range; pmf sums to <= ~1 (leftover quirk can only lower it)
+        assert a["alias_index"].max() < w * h
+
+
+def test_synthetic_environment_golden_64x32():
+    g = np.load(os.path.join(util.ROOT, "tests", "golden", "env_64x32.npz"))
+    env = R.Environment.synthetic(64, 32)
+    assert np.array_equal(util.bits(env.rgba), util.bits(g["rgba"]))
+    assert np.array_equal(env.alias.view(np.uint32).reshape(-1, 4), g["alias"])
+    assert env.rgba[..., :3].min() > 0 and np.isfinite(env.rgba).all() and np.all(env.rgba[..., 3] == 0)
+
+
+def test_plane_and_camera_uniforms_match_oracle():
+    rng = np.random.default_rng(5)
+    pls = np.zeros(20, T.PLANE_DESC)
+    pls["pos"] = rng.uniform(-5, 5, (20, 3))
+    pls["forward"] = rng.uniform(-3, 3, (20, 3))
+    pls["right"] = rng.uniform(-3, 3, (20, 3))
+    pls["material_id"] = rng.integers(0, 5, 20)
+    assert util.fields_equal(R.plane_to_uniform(pls), oracle.plane_to_uniform(pls.view(oracle.PLANE_SRC)))
+    for _ in range(20):
+        pos, yaw, pitch, fov = rng.uniform(-3, 3, 3), rng.uniform(-3, 3), rng.uniform(-1.5, 1.5), rng.uniform(0.3, 2.5)
+        a = R.camera_uniform(host.make_camera_desc(pos, yaw, pitch, fov))
+        b = oracle.camera_uniform(pos, float(np.float32(yaw)), float(np.float32(pitch)), float(np.float32(fov)))
+        assert util.fields_equal(a, b)
+
+
+def test_loader_errors_use_reference_messages(tmp_path):
+    with pytest.raises(R.SceneError, match="Couldn't open scene"):
+        R.Scene.load_toml(str(tmp_path / "missing.toml"))
+    bad = tmp_path / "bad.toml"
+    bad.write_text("[[material]]\nname = \"a\"\ncolor = [1,1,1]\nroughness = 1\nmetallic = 0\nemission = [0,0,0]\n"
+                   "[[object]]\n[object.Sphere]\nmaterial = \"nope\"\npos = [0,0,0]\nradius = 1\n"
+                   "[camera]\npos = [0,0,0]\nyaw = 0\npitch = 0\nfov_y = 90\n")
+    with pytest.raises(R.SceneError, match=r"Error in object 0 \(Sphere\): Material 'nope' does not exist\.\n  --> "):
+        R.Scene.load_toml(str(bad))
+    bad.write_text("[[material]]\nname = 3\n")
+    with pytest.raises(R.SceneError, match="Couldn't parse scene"):
+        R.Scene.load_toml(str(bad))
+    bad.write_text("[[material]]\nname = \"a\"\ncolor = [1,1,1]\nroughness = 1\nmetallic = 0\nemission = [0,0,0]\n"
+                   "[[object]]\n[object.Mesh]\nmaterial = \"a\"\npath = \"nothing.obj\"\n"
+                   "[camera]\npos = [0,0,0]\nyaw = 0\npitch = 0\nfov_y = 90\n")
+    with pytest.raises(R.SceneError, match=r"Error in object 0 \(Mesh\): Cannot open 'nothing.obj'"):
+        R.Scene.load_toml(str(bad))
+
+
+def test_first_material_name_wins_and_ints_accepted(tmp_path):
+    p = tmp_path / "s.toml"
+    p.write_text("[[material]]\nname = \"m\"\ncolor = [1, 0, 0]\nroughness = 1\nmetallic = 0\nemission = [0, 0, 0]\n"
+                 "[[material]]\nname = \"m\"\ncolor = [0, 1, 0]\nroughness = 0.5\nmetallic = 1\nemission = [0, 0, 0]\n"
+                 "[[object]]\n[object.Sphere]\nmaterial = \"m\"\npos = [ 0, 1, -2 ] # comment\nradius = 1\n"
+                 "[camera]\npos = [\n 0.0,\n 1.0,\n 3.0,\n]\nyaw = 0\npitch = 0\nfov_y = 100\n")
+    s = R.Scene.load_toml(str(p))
+    assert s.spheres["material_id"][0] == 0 and len(s.materials) == 2
+    assert s.camera_desc["fov_y"][0] == np.float32(100) * np.float32(np.pi / 180)
