@@ -144,6 +144,10 @@ typedef struct rsrt_hit {
 rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n_rays, const float *origins_xyz, const float *directions_xyz,
                            uint32_t mode, uint32_t flags, rsrt_hit *out);
 
+/* Diagnostic words of an instrumented build (-DRT_INSTRUMENT: loop-trip counters behind
+ * tools/simd_efficiency.py); all zero in the product build. Cumulative since context creation. */
+rsrt_status rsrt_get_debug_counters(rsrt_context *ctx, uint64_t out[32]);
+
 /* Library / device description, for logs: "librsrt <version>; <device name>; <CUs> CUs". */
 const char *rsrt_describe(rsrt_context *ctx);
 

@@ -45,12 +45,18 @@ def hipcc_path():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def build_hip(force=False, extra_flags=()):
+def build_hip(force=False, extra_flags=(), instrument=False):
+    """librsrt.so; instrument=True builds the diagnostic twin librsrt_instr.so (-DRT_INSTRUMENT)."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    if force or _newer(HIP_LIB, _deps("hip")):
+    target = HIP_LIB.replace(".so", "_instr.so") if instrument else HIP_LIB
+    flags = list(extra_flags) + (["-DRT_INSTRUMENT"] if instrument else [])
+    if os.environ.get("RSRT_LEAFQ"):  # experiment knob: leaves a lane holds before the wave tests primitives
+        flags.append("-DRT_LEAFQ=" + os.environ["RSRT_LEAFQ"])
+        force = True
+    if force or _newer(target, _deps("hip")):
         _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-              "-fno-fast-math", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", INCLUDE, "-o", HIP_LIB] + list(extra_flags) + srcs)
-    return HIP_LIB
+              "-fno-fast-math", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", INCLUDE, "-o", target] + flags + srcs)
+    return target
 
 
 def build_all(force=False):

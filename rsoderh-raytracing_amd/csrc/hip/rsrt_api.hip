@@ -28,6 +28,7 @@
 #include "rt_device.h"
 
 #define RT_BLOCK 256
+#define RT_STATS_WORDS 40 // paths, ext, shadow + 32 diagnostic words (zero in the product build)
 #define RT_WAVE 64
 
 struct RenderParams {
@@ -42,6 +43,8 @@ struct RenderParams {
     uint32_t tile_w, tile_h, tiles_x, n_tiles, rank, world, n_owned_tiles;
     uint32_t samples_per_chunk, n_sblocks, n_chunks;
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
+    uint32_t trace_budget;
+    uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
     float *sample_buf;
     unsigned int *work_counter;
     unsigned long long *stats; // paths, ext_rays, shadow_rays
@@ -60,12 +63,13 @@ __device__ __forceinline__ SceneView<true> make_view<true>(const DevScene &sc)
     v.o_mats = v.o_trin + 3u * sc.n_tris;
     v.o_fbs = v.o_mats + 4u * sc.n_materials;
     v.o_fbp = v.o_fbs + 4u * sc.n_spheres;
+    v.o_esc = v.o_fbp + 4u * sc.n_planes;
     return v;
 }
 template <>
 __device__ __forceinline__ SceneView<false> make_view<false>(const DevScene &sc)
 {
-    return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes};
+    return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.escape};
 }
 
 // Copies the scene image into LDS (the six arrays are contiguous in one device allocation, in
@@ -260,6 +264,8 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
     }
 }
 
+#include "rt_wavepool.h"
+
 // total = textureLoad(cumulative) + sample, once per sample in order (shader.wgsl:1367-1371)
 __global__ __launch_bounds__(RT_BLOCK) void rt_resolve_kernel(RenderParams P, float4 *accum)
 {
@@ -355,6 +361,8 @@ struct rsrt_context {
     // work buffers
     float *sample_buf = nullptr;
     size_t sample_buf_bytes = 0;
+    uint32_t *cold_state = nullptr;
+    size_t cold_bytes = 0;
     unsigned int *work_counter = nullptr;
     unsigned long long *dev_stats = nullptr;
     // stats
@@ -364,8 +372,11 @@ struct rsrt_context {
     std::vector<PassEvents> pending_events;
     double trace_ms_acc = 0, resolve_ms_acc = 0;
     std::vector<hipEvent_t> event_pool;
-    int blocks_per_cu_lds = 0, blocks_per_cu_glb = 0;
+    int blocks_per_cu[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // [lds][kernel variant]
+    int kernel_variant = 2; // 0 megakernel, 1..3 wave-pool with 64/128/192 slots per wave
+    uint32_t trace_budget = 24; // traversal steps per TRACE invocation before a ray is re-queued
     uint32_t launches_pending = 0;
+    unsigned long long debug_words[32] = {0};
 };
 
 namespace {
@@ -485,7 +496,7 @@ rsrt_status collect_stats(rsrt_context *ctx)
     ctx->pending_events.clear();
     ctx->stats.trace_kernel_ms = trace_ms;
     ctx->stats.resolve_kernel_ms = resolve_ms;
-    unsigned long long c[3] = {0, 0, 0}; // device counters are cumulative
+    unsigned long long c[RT_STATS_WORDS] = {0}; // device counters are cumulative
     HIP_TRY(ctx, hipMemcpy(c, ctx->dev_stats, sizeof c, hipMemcpyDeviceToHost));
     ctx->stats.paths = c[0] - ctx->stats.total_paths;
     ctx->stats.ext_rays = c[1] - ctx->stats.total_ext_rays;
@@ -497,6 +508,7 @@ rsrt_status collect_stats(rsrt_context *ctx)
     ctx->stats.total_kernel_ms += ms;
     ctx->stats.launches = ctx->launches_pending;
     ctx->launches_pending = 0;
+    memcpy(ctx->debug_words, c + 3, sizeof ctx->debug_words);
     ctx->stats_pending = false;
     return RSRT_OK;
 }
@@ -524,14 +536,22 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     DeviceGuard g(device_index);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc(&ctx->work_counter, sizeof(unsigned int))) != hipSuccess ||
-        (e = hipMalloc(&ctx->dev_stats, 3 * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMemset(ctx->dev_stats, 0, 3 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc(&ctx->dev_stats, RT_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(ctx->dev_stats, 0, RT_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess) {
         fail(nullptr, RSRT_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
         delete ctx;
         return RSRT_ERR_HIP;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_render_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void *big_lds[] = {reinterpret_cast<const void *>(&rt_render_kernel<true>), reinterpret_cast<const void *>(&rt_render_kernel<false>),
+                             reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 64>), reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 64>),
+                             reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 128>), reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 128>),
+                             reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192>), reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192>)};
+    for (const void *f : big_lds) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (const char *kv = getenv("RSRT_KERNEL")) { // 0 = lockstep megakernel, 1/2/3 = wave-pool kernel with 64/128/192 slots per wave
+        int v = atoi(kv);
+        if (v >= 0 && v <= 3) ctx->kernel_variant = v;
+    }
+    if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_cast_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
     snprintf(buf, sizeof buf, "librsrt 0.1; %s (%s); %d CUs", prop.name, prop.gcnArchName, ctx->cus);
@@ -551,6 +571,7 @@ void rsrt_context_destroy(rsrt_context *ctx)
     for (auto &e : ctx->envs) { (void)hipFree(e.rgba); (void)hipFree(e.alias); }
     (void)hipFree(ctx->accum_owned);
     (void)hipFree(ctx->sample_buf);
+    (void)hipFree(ctx->cold_state);
     (void)hipFree(ctx->work_counter);
     (void)hipFree(ctx->dev_stats);
     (void)hipStreamDestroy(ctx->stream);
@@ -617,8 +638,28 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
             }
         }
     }
-    // ---- build the device image: nodes | prims | tri normals | materials | fb spheres | fb planes
-    const size_t n_f4 = 2ull * n_nodes + 4ull * n_primitives + 3ull * n_triangles + 4ull * n_materials + 4ull * n_spheres + 4ull * n_planes;
+    // ---- threaded traversal links: escape[octant][node] (rt_device.h, trace_threaded)
+    std::vector<uint32_t> escape(8ull * n_nodes, RT_END);
+    for (uint32_t q = 0; q < 8; q++) {
+        std::vector<std::pair<uint32_t, uint32_t>> st; // node, its escape
+        st.push_back({0u, RT_END});
+        while (!st.empty()) {
+            auto [i, esc] = st.back();
+            st.pop_back();
+            escape[(size_t)q * n_nodes + i] = esc;
+            const rsrt_bvh_node &nd = nodes[i];
+            if (nd.primitives_len == 0) {
+                const bool far_first = (q >> nd.split_axis) & 1u; // sign(inv_dir[axis]) < 0: second child is nearer
+                const uint32_t first = i + 1, second = nd.primitives_or_second_child_index;
+                const uint32_t near_c = far_first ? second : first, far_c = far_first ? first : second;
+                st.push_back({near_c, far_c});
+                st.push_back({far_c, esc});
+            }
+        }
+    }
+    const size_t esc_f4 = (8ull * n_nodes + 3) / 4;
+    // ---- build the device image: nodes | prims | tri normals | materials | fb spheres | fb planes | escape links
+    const size_t n_f4 = 2ull * n_nodes + 4ull * n_primitives + 3ull * n_triangles + 4ull * n_materials + 4ull * n_spheres + 4ull * n_planes + esc_f4;
     std::vector<float4> img(n_f4);
     float4 *p = img.data();
     float4 *p_nodes = p;
@@ -647,6 +688,8 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     for (uint32_t i = 0; i < n_spheres; i++, p += 4) make_sphere_record(spheres[i], p);
     float4 *p_fbp = p;
     for (uint32_t i = 0; i < n_planes; i++, p += 4) make_plane_record(planes[i], p);
+    float4 *p_esc = p;
+    memcpy(p_esc, escape.data(), escape.size() * sizeof(uint32_t));
 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->scene_blob) { (void)hipFree(ctx->scene_blob); ctx->scene_blob = nullptr; }
@@ -660,12 +703,13 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.materials = ctx->scene_blob + (p_mats - img.data());
     sc.fb_spheres = ctx->scene_blob + (p_fbs - img.data());
     sc.fb_planes = ctx->scene_blob + (p_fbp - img.data());
+    sc.escape = ctx->scene_blob + (p_esc - img.data());
     sc.n_nodes = n_nodes; sc.n_prims = n_primitives; sc.n_tris = n_triangles; sc.n_materials = n_materials;
     sc.n_spheres = n_spheres; sc.n_planes = n_planes;
     sc.stack_entries = depth + 1;
     const size_t stack_bytes = (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t);
     if (stack_bytes > 128 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh depth %u exceeds the supported traversal stack", depth);
-    sc.lds_float4s = (n_f4 * sizeof(float4) + stack_bytes <= lds_limit_bytes()) ? (uint32_t)n_f4 : 0u;
+    sc.lds_float4s = (n_f4 * sizeof(float4) <= 24 * 1024) ? (uint32_t)n_f4 : 0u; // LDS image only while it leaves room for the path pools
     ctx->scene_ready = true;
     return RSRT_OK;
 }
@@ -808,6 +852,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     if ((uint64_t)P.n_owned_tiles * tile_px > 0x7fffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "frame too large");
     P.n_slots = P.n_owned_tiles * tile_px;
     P.work_counter = ctx->work_counter;
+    P.trace_budget = ctx->trace_budget;
     P.stats = ctx->dev_stats;
     if (P.n_slots == 0) return RSRT_OK;
 
@@ -826,16 +871,42 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.sample_buf = ctx->sample_buf;
 
     const bool lds = P.scene.lds_float4s != 0;
-    const size_t smem = (size_t)P.scene.lds_float4s * sizeof(float4) + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t);
-    int &bpc = lds ? ctx->blocks_per_cu_lds : ctx->blocks_per_cu_glb;
+    const int kv = ctx->kernel_variant;
+    const uint32_t pool = kv == 1 ? 64u : (kv == 2 ? 128u : 192u);
+    const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
+    const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
+                                : scene_bytes + (size_t)(RT_BLOCK / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
+    if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
+    const void *kfn = nullptr;
+    switch (kv * 2 + (lds ? 1 : 0)) {
+    case 0: kfn = reinterpret_cast<const void *>(&rt_render_kernel<false>); break;
+    case 1: kfn = reinterpret_cast<const void *>(&rt_render_kernel<true>); break;
+    case 2: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 64>); break;
+    case 3: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 64>); break;
+    case 4: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 128>); break;
+    case 5: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 128>); break;
+    case 6: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192>); break;
+    default: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192>); break;
+    }
+    int &bpc = ctx->blocks_per_cu[lds ? 1 : 0][kv];
     if (bpc == 0) {
         int nb = 0;
-        hipError_t e = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_render_kernel<true>, RT_BLOCK, smem)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_render_kernel<false>, RT_BLOCK, smem);
-        if (e != hipSuccess || nb <= 0) nb = 2;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, RT_BLOCK, smem);
+        if (e != hipSuccess || nb <= 0) nb = 1;
         bpc = std::min(nb, 8);
+        if (const char *o = getenv("RSRT_BLOCKS_PER_CU")) { int v = atoi(o); if (v > 0) bpc = std::min(bpc, v); } // experiment knob
     }
 
+    if (kv != 0) { // cold path-state arena: one block of columns per wave that can be resident
+        const size_t need_cold = (size_t)ctx->cus * bpc * (RT_BLOCK / RT_WAVE) * C_COUNT * pool * sizeof(uint32_t);
+        if (need_cold > ctx->cold_bytes) {
+            HIP_TRY(ctx, hipStreamSynchronize(stream));
+            if (ctx->cold_state) { (void)hipFree(ctx->cold_state); ctx->cold_state = nullptr; ctx->cold_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(&ctx->cold_state, need_cold));
+            ctx->cold_bytes = need_cold;
+        }
+        P.cold_state = ctx->cold_state;
+    }
     hipEvent_t last_end = nullptr;
     for (uint32_t done = 0; done < sample_count; done += pass_samples) {
         rsrt_context::PassEvents pe = {get_event(ctx), get_event(ctx), get_event(ctx)};
@@ -853,9 +924,8 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
             const uint32_t waves_wanted = (uint32_t)std::min<uint64_t>(n_chunks, 0x7fffffffull);
             uint32_t grid = std::min<uint32_t>((waves_wanted + 3) / 4, (uint32_t)(ctx->cus * bpc));
             grid = std::max(grid, 1u);
-            if (lds) hipLaunchKernelGGL(rt_render_kernel<true>, dim3(grid), dim3(RT_BLOCK), smem, stream, P);
-            else hipLaunchKernelGGL(rt_render_kernel<false>, dim3(grid), dim3(RT_BLOCK), smem, stream, P);
-            HIP_TRY(ctx, hipGetLastError());
+            void *kargs[] = {&P};
+            HIP_TRY(ctx, hipLaunchKernel(kfn, dim3(grid), dim3(RT_BLOCK), kargs, smem, stream));
             ctx->launches_pending++;
         } else {
             HIP_TRY(ctx, hipMemsetAsync(ctx->sample_buf, 0, per_sample * P.sample_count, stream));
@@ -891,6 +961,17 @@ rsrt_status rsrt_get_stats(rsrt_context *ctx, rsrt_stats *out)
     rsrt_status st = collect_stats(ctx);
     if (st) return st;
     *out = ctx->stats;
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_get_debug_counters(rsrt_context *ctx, uint64_t out[32])
+{
+    if (!ctx || !out) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    ctx->stats_pending = true; // force a read-back of the device words
+    rsrt_status st = collect_stats(ctx);
+    if (st) return st;
+    for (int i = 0; i < 32; i++) out[i] = ctx->debug_words[i];
     return RSRT_OK;
 }
 

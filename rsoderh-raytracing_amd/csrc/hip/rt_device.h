@@ -19,6 +19,22 @@
 #pragma once
 #include "rt_math.h"
 
+// Diagnostic build only (-DRT_INSTRUMENT, librsrt_instr.so): per-lane counters of loop trips, folded
+// into SIMD-efficiency figures by tools/simd_efficiency.py.  No counter exists in the product build.
+#ifdef RT_INSTRUMENT
+#define RT_DBG_N 32
+struct DbgCounters { unsigned long long c[RT_DBG_N]; };
+#define DBG_DECL DbgCounters &dbg,
+#define DBG_ARG dbg,
+#define DBG_ADD(i, v) dbg.c[i] += (v)
+#define DBG_WAVE_TICK(i) do { if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) dbg.c[i] += 1; } while (0)
+#else
+#define DBG_DECL
+#define DBG_ARG
+#define DBG_ADD(i, v) do { } while (0)
+#define DBG_WAVE_TICK(i) do { } while (0)
+#endif
+
 #define RT_INFINITY 1.70141183460469231732e+38f // shader.wgsl:235
 #define RT_PI ((float)3.14159)                   // shader.wgsl:239
 #define RT_INV_PI ((float)(1.0 / 3.14159))       // :240, const-evaluated in abstract float
@@ -34,6 +50,7 @@ struct DevScene {
     const float4 *materials;   // 4 per material
     const float4 *fb_spheres;  // 4 per sphere, scene order (cast_ray's brute-force loop)
     const float4 *fb_planes;   // 4 per plane
+    const float4 *escape;      // 8 octants x n_nodes u32 'next node when this subtree is done', packed 4 per float4
     uint32_t n_nodes, n_prims, n_tris, n_materials, n_spheres, n_planes;
     uint32_t stack_entries;    // per-lane traversal stack entries (tree depth + 1)
     uint32_t lds_float4s;      // float4 count of the LDS image (0 = scene stays in global memory)
@@ -53,23 +70,26 @@ extern __shared__ float4 rt_smem[];
 
 template <>
 struct SceneView<true> {
-    uint32_t o_nodes, o_prims, o_trin, o_mats, o_fbs, o_fbp;
+    uint32_t o_nodes, o_prims, o_trin, o_mats, o_fbs, o_fbp, o_esc;
     RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
     RT_DEV float4 prim(uint32_t i) const { return rt_smem[o_prims + i]; }
     RT_DEV float4 trin(uint32_t i) const { return rt_smem[o_trin + i]; }
     RT_DEV float4 mat(uint32_t i) const { return rt_smem[o_mats + i]; }
     RT_DEV float4 fbs(uint32_t i) const { return rt_smem[o_fbs + i]; }
-    RT_DEV float4 fbp(uint32_t i) const { return rt_smem[o_fbp + i]; }
+    // record k of the primitive array named by src (SRC_BVH / SRC_FB_SPHERE / SRC_FB_PLANE)
+    RT_DEV float4 rec(uint32_t src, uint32_t i) const { return rt_smem[(src == SRC_BVH ? o_prims : (src == SRC_FB_SPHERE ? o_fbs : o_fbp)) + i]; }
+    RT_DEV uint32_t esc(uint32_t i) const { return reinterpret_cast<const uint32_t *>(rt_smem + o_esc)[i]; }
 };
 template <>
 struct SceneView<false> {
-    const float4 *nodes, *prims, *tri_normals, *materials, *fb_spheres, *fb_planes;
+    const float4 *nodes, *prims, *tri_normals, *materials, *fb_spheres, *fb_planes, *escape;
     RT_DEV float4 node(uint32_t i) const { return nodes[i]; }
     RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
     RT_DEV float4 trin(uint32_t i) const { return tri_normals[i]; }
     RT_DEV float4 mat(uint32_t i) const { return materials[i]; }
     RT_DEV float4 fbs(uint32_t i) const { return fb_spheres[i]; }
-    RT_DEV float4 fbp(uint32_t i) const { return fb_planes[i]; }
+    RT_DEV float4 rec(uint32_t src, uint32_t i) const { return (src == SRC_BVH ? prims : (src == SRC_FB_SPHERE ? fb_spheres : fb_planes))[i]; }
+    RT_DEV uint32_t esc(uint32_t i) const { return reinterpret_cast<const uint32_t *>(escape)[i]; }
 };
 
 // ------------------------------------------------------------------ RNG (shader.wgsl:605-631)
@@ -160,8 +180,7 @@ struct Surface {
 template <class View>
 RT_DEV float4 hit_record(const View &S, const Hit &h, uint32_t k)
 {
-    uint32_t i = 4u * h.ref + k;
-    return h.src == SRC_BVH ? S.prim(i) : (h.src == SRC_FB_SPHERE ? S.fbs(i) : S.fbp(i));
+    return S.rec(h.src, 4u * h.ref + k);
 }
 
 // The HitInfo fields the shader fills at every accepted test (shader.wgsl:335-359, :393-405,
@@ -202,18 +221,18 @@ template <class View>
 RT_DEV float test_record(const View &S, uint32_t rec, uint32_t src, V3 o, V3 d, float &u, float &v)
 {
     uint32_t i = 4u * rec;
-    float4 r0 = src == SRC_BVH ? S.prim(i) : (src == SRC_FB_SPHERE ? S.fbs(i) : S.fbp(i));
-    float4 r1 = src == SRC_BVH ? S.prim(i + 1) : (src == SRC_FB_SPHERE ? S.fbs(i + 1) : S.fbp(i + 1));
+    float4 r0 = S.rec(src, i);
+    float4 r1 = S.rec(src, i + 1);
     uint32_t type = as_u(r0.w) & 3u;
     V3 p0 = v3(r0.x, r0.y, r0.z);
     if (type == PRIM_TRIANGLE) {
-        float4 r2 = S.prim(i + 2);
+        float4 r2 = S.rec(src, i + 2);
         return triangle_t(o, d, p0, v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), u, v);
     } else if (type == PRIM_SPHERE) {
         return sphere_t(o, d, p0, r1.y);
     } else {
-        float4 r2 = src == SRC_BVH ? S.prim(i + 2) : S.fbp(i + 2);
-        float4 r3 = src == SRC_BVH ? S.prim(i + 3) : S.fbp(i + 3);
+        float4 r2 = S.rec(src, i + 2);
+        float4 r3 = S.rec(src, i + 3);
         return plane_t(o, d, p0, v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), v3(r3.x, r3.y, r3.z));
     }
 }
@@ -520,4 +539,198 @@ RT_DEV float power_heuristic(float a, float b) // :1206-1210
 {
     float a2 = a * a, b2 = b * b;
     return a2 / (a2 + b2);
+}
+
+// ------------------------------------------------------------------ while-while traversal
+// Same visit order, same tests, same strict-< replacement as trace_bvh (so the same result),
+// organised for wave64 lockstep: every lane first walks interior nodes until it HOLDS a leaf
+// (lanes that found theirs wait), then all holders test their leaf's primitives together.
+// `anyhit` is per lane: an extension ray and an NEE shadow ray can share the loop.
+template <class View>
+RT_DEV void trace_ww(DBG_DECL const View &S, V3 o, V3 d, bool prune, bool anyhit, uint32_t *stack, uint32_t stride, Hit &h)
+{
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    h.t = RT_INFINITY;
+    h.ref = 0;
+    h.src = SRC_BVH;
+    h.u = h.v = 0.0f;
+    uint32_t sp = 0, cur = 0;
+    bool alive = true;
+    while (alive) {
+        uint32_t leaf_idx = 0, leaf_len = 0;
+        // ---- descend until this lane holds a leaf or its stack runs dry
+        DBG_WAVE_TICK(14);
+        while (alive && leaf_len == 0u) {
+            DBG_WAVE_TICK(10);
+            DBG_ADD(11, 1);
+            float4 n0 = S.node(2u * cur), n1 = S.node(2u * cur + 1u);
+            float t_0 = 0.0f, t_1 = RT_INFINITY;
+            bool inside = true;
+            {
+                float tn = (n0.x - o.x) * inv.x, tf = (n1.x - o.x) * inv.x;
+                if (tn > tf) { float s = tn; tn = tf; tf = s; }
+                if (tn > t_0) t_0 = tn;
+                if (tf < t_1) t_1 = tf;
+                if (t_0 > t_1) inside = false;
+            }
+            if (inside) {
+                float tn = (n0.y - o.y) * inv.y, tf = (n1.y - o.y) * inv.y;
+                if (tn > tf) { float s = tn; tn = tf; tf = s; }
+                if (tn > t_0) t_0 = tn;
+                if (tf < t_1) t_1 = tf;
+                if (t_0 > t_1) inside = false;
+            }
+            if (inside) {
+                float tn = (n0.z - o.z) * inv.z, tf = (n1.z - o.z) * inv.z;
+                if (tn > tf) { float s = tn; tn = tf; tf = s; }
+                if (tn > t_0) t_0 = tn;
+                if (tf < t_1) t_1 = tf;
+                if (t_0 > t_1) inside = false;
+            }
+            if (inside && prune && t_0 > h.t) inside = false;
+            const uint32_t idx = as_u(n0.w), la = as_u(n1.w);
+            const uint32_t len = la & 0xffffu, axis = la >> 16;
+            if (inside && len > 0u) {
+                leaf_idx = idx;
+                leaf_len = len;
+            } else if (inside) {
+                const bool far_first = comp(inv, axis) < 0.0f;
+                stack[sp * stride] = far_first ? cur + 1u : idx;
+                sp++;
+                cur = far_first ? idx : cur + 1u;
+            } else if (sp == 0u) {
+                alive = false;
+            } else {
+                sp--;
+                cur = stack[sp * stride];
+            }
+        }
+        // ---- test the held leaf
+        if (leaf_len != 0u) {
+            for (uint32_t i = 0; i < leaf_len; i++) {
+                DBG_WAVE_TICK(12);
+                DBG_ADD(13, 1);
+                float u, v;
+                float t = test_record(S, leaf_idx + i, SRC_BVH, o, d, u, v);
+                if (t >= 0.0f && t < h.t) {
+                    h.t = t;
+                    h.ref = leaf_idx + i;
+                    h.u = u;
+                    h.v = v;
+                    if (anyhit) { alive = false; break; }
+                }
+            }
+            if (alive) {
+                if (sp == 0u) alive = false;
+                else { sp--; cur = stack[sp * stride]; }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ threaded (stackless) traversal
+// For a fixed sign octant of the ray direction the reference's depth-first order (near child by
+// sign(inv_dir[split_axis]), shader.wgsl:536-547) is a FIXED sequence, so it can be threaded at
+// upload: escape[octant][node] = the node the stack would pop to once `node`'s subtree is done
+// (the far sibling for a near child, the parent's escape for a far child, RT_END at the end).
+// Same boxes, same primitives, same order, same strict-< replacement as cast_ray_bvh — but the only
+// traversal state is `cur`, so a traversal can stop after `budget` steps and be resumed later by
+// any lane (h carries the best hit so far).
+#define RT_END 0xffffffffu
+#ifndef RT_LEAFQ
+#define RT_LEAFQ 3
+#endif
+// A lane keeps descending until it holds RT_LEAFQ leaves (or its traversal ends) before the wave
+// switches to primitive testing: fewer and better-filled rounds than one leaf per round.  Leaves are
+// tested in the order they were found, so the winner of a tie is unchanged; nodes entered while
+// leaves wait are pruned against a slightly older best t (never wrongly: a node skipped by the
+// reference's fresher bound cannot hold a closer hit), which is why this stays result-preserving.
+template <class View>
+RT_DEV void trace_threaded(DBG_DECL const View &S, uint32_t n_nodes, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget,
+                           uint32_t &cur, Hit &h)
+{
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    const uint32_t ebase = octant * n_nodes;
+    uint32_t steps = 0;
+    while (cur != RT_END && steps < budget) {
+        DBG_WAVE_TICK(14);
+        uint32_t qi[RT_LEAFQ], ql[RT_LEAFQ]; // held leaves: first primitive record, primitive count
+        uint32_t nq = 0;
+#pragma unroll
+        for (int j = 0; j < RT_LEAFQ; j++) qi[j] = ql[j] = 0u;
+        while (cur != RT_END && nq < RT_LEAFQ) {
+            DBG_WAVE_TICK(10);
+            DBG_ADD(11, 1);
+            steps++;
+            const float4 n0 = S.node(2u * cur), n1 = S.node(2u * cur + 1u);
+            float t_0 = 0.0f, t_1 = RT_INFINITY;
+            bool inside = true;
+            {
+                float tn = (n0.x - o.x) * inv.x, tf = (n1.x - o.x) * inv.x;
+                if (tn > tf) { float s = tn; tn = tf; tf = s; }
+                if (tn > t_0) t_0 = tn;
+                if (tf < t_1) t_1 = tf;
+                if (t_0 > t_1) inside = false;
+            }
+            if (inside) {
+                float tn = (n0.y - o.y) * inv.y, tf = (n1.y - o.y) * inv.y;
+                if (tn > tf) { float s = tn; tn = tf; tf = s; }
+                if (tn > t_0) t_0 = tn;
+                if (tf < t_1) t_1 = tf;
+                if (t_0 > t_1) inside = false;
+            }
+            if (inside) {
+                float tn = (n0.z - o.z) * inv.z, tf = (n1.z - o.z) * inv.z;
+                if (tn > tf) { float s = tn; tn = tf; tf = s; }
+                if (tn > t_0) t_0 = tn;
+                if (tf < t_1) t_1 = tf;
+                if (t_0 > t_1) inside = false;
+            }
+            if (inside && prune && t_0 > h.t) inside = false;
+            const uint32_t idx = as_u(n0.w), la = as_u(n1.w);
+            const uint32_t len = la & 0xffffu, axis = la >> 16;
+            if (inside && len == 0u) {
+                cur = ((octant >> axis) & 1u) ? idx : cur + 1u; // near child first
+            } else {
+                if (inside) {
+#pragma unroll
+                    for (int j = 0; j < RT_LEAFQ; j++) {
+                        qi[j] = (nq == (uint32_t)j) ? idx : qi[j];
+                        ql[j] = (nq == (uint32_t)j) ? len : ql[j];
+                    }
+                    nq++;
+                }
+                cur = S.esc(ebase + cur); // subtree (or leaf) done: continue where the stack would pop to
+            }
+        }
+        // ---- test the held leaves in the order found
+        uint32_t j = 0, i = 0;
+        uint32_t leaf_i = qi[0], leaf_l = ql[0];
+        while (j < nq) {
+            DBG_WAVE_TICK(12);
+            DBG_ADD(13, 1);
+            steps++;
+            const uint32_t rec = leaf_i + i;
+            float u, v;
+            const float t = test_record(S, rec, SRC_BVH, o, d, u, v);
+            if (t >= 0.0f && t < h.t) {
+                h.t = t;
+                h.ref = rec;
+                h.u = u;
+                h.v = v;
+                if (anyhit) { cur = RT_END; break; }
+            }
+            i++;
+            if (i == leaf_l) {
+                i = 0;
+                j++;
+#pragma unroll
+                for (int k = 1; k < RT_LEAFQ; k++) {
+                    leaf_i = (j == (uint32_t)k) ? qi[k] : leaf_i;
+                    leaf_l = (j == (uint32_t)k) ? ql[k] : leaf_l;
+                }
+            }
+        }
+    }
 }

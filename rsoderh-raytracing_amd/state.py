@@ -21,7 +21,7 @@ FLAG_REFERENCE_TRAVERSAL = 1
 _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "rsrt_upload_scene",
             "rsrt_upload_environment", "rsrt_set_partition", "rsrt_accumulator_resize", "rsrt_accumulator_bind",
             "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_render",
-            "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe"]
+            "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters"]
 
 
 class RsrtError(RuntimeError):
@@ -46,7 +46,8 @@ def lib():
     global _lib
     if _lib is None:
         try:
-            path = _build.build_hip()
+            import os
+            path = _build.build_hip(instrument=os.environ.get("RSRT_INSTRUMENT") == "1")
             L = C.CDLL(path)
         except Exception as e:  # noqa: BLE001
             raise RsrtError("librsrt.so (the HIP integrator) is not available: %s" % e) from e
@@ -69,6 +70,7 @@ def lib():
         L.rsrt_render.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p]
         L.rsrt_synchronize.argtypes = [C.c_void_p]
         L.rsrt_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.rsrt_get_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.rsrt_cast_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib = L
     return _lib
@@ -211,6 +213,11 @@ class State:
         s = Stats()
         self._check(self._L.rsrt_get_stats(self._ctx, C.byref(s)), "rsrt_get_stats")
         return s.as_dict()
+
+    def debug_counters(self):
+        out = np.zeros(32, np.uint64)
+        self._check(self._L.rsrt_get_debug_counters(self._ctx, _p(out)), "rsrt_get_debug_counters")
+        return out
 
     def cast_rays(self, origins, directions, mode=0, flags=0):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)

@@ -1,0 +1,26 @@
+"""Diagnostic: SIMD efficiency per code region of the wave-pool kernel, from the loop-trip counters of
+the instrumented build (RSRT_INSTRUMENT=1).  python tools/simd_efficiency.py [kernel_variant] [spp]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+os.environ['RSRT_INSTRUMENT'] = '1'
+os.environ['RSRT_KERNEL'] = sys.argv[1] if len(sys.argv) > 1 else '2'
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+import numpy as np
+import util
+import rsoderh_raytracing_amd as R
+env = R.Environment.synthetic(2048, 1024)
+sc = R.Scene.load_toml(util.scene_path(sys.argv[3] if len(sys.argv) > 3 else 'house'))
+st = R.State.new(sc, env, 1920, 1080); st.max_bounces = 8
+st.render_range(0, spp); st.synchronize()
+g = st.stats(); c = st.debug_counters().astype(np.float64)
+names = ['GEN', 'TRACE', 'MISS', 'SHADE', 'BSDF']
+print('kernel variant', os.environ['RSRT_KERNEL'], 'trace kernel %.1f ms' % g['trace_kernel_ms'], 'rays', g['ext_rays'] + g['shadow_rays'])
+for i, n in enumerate(names):
+    if c[i]:
+        print('  stage %-5s invocations %12.0f  avg lanes %.1f / 64' % (n, c[i], c[5 + i] / c[i]))
+rays = g['ext_rays'] + g['shadow_rays']
+print('  trace: outer trips/wave-invocation %.2f' % (c[14] / max(c[1], 1)))
+print('  descend loop: wave trips %.3e, lane trips %.3e -> efficiency %.1f%% of 64 lanes ; nodes/ray %.2f' % (c[10], c[11], 100 * c[11] / max(64 * c[10], 1), c[11] / rays))
+print('  leaf loop   : wave trips %.3e, lane trips %.3e -> efficiency %.1f%% ; prim tests/ray %.2f' % (c[12], c[13], 100 * c[13] / max(64 * c[12], 1), c[13] / rays))
+print('  per TRACE invocation: descend wave trips %.1f, leaf wave trips %.1f' % (c[10] / max(c[1], 1), c[12] / max(c[1], 1)))
