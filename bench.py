@@ -31,7 +31,7 @@ COUNTS_FILE = os.path.join(ROOT, "profiles", "algo_counts_house_1080p_8b.json")
 
 
 def algorithmic_bytes(st):
-    """SURVEY.md §8(d) per-unit figures applied to instrumented counts (pruned traversal).
+    """SURVEY.md §8(d) per-unit figures applied to instrumented counts (unpruned, any-hit shadow).
     Returns bytes for everything in `st` except the once-per-pixel accumulator write."""
     rays = st["ext_rays"] + st["shadow_rays"]
     b = 32 * st["nodes_visited"] + 8 * st["prim_refs"]
@@ -48,18 +48,22 @@ def cpu_leg(scene, env, width, height, bounces, log):
     import util
     osc, oenv, cam = util.oracle_scene(scene), util.oracle_env(env), scene.camera_uniform().view(oracle.CAMERA)
     cores = os.cpu_count() or 1
-    # counts for the roofline: pruned + any-hit traversal (the minimal work yielding the same image)
+    # counts for the roofline: the traversal the kernel executes — every node the reference visits for
+    # extension rays, any-hit exit for shadow rays (pruning is not exactly result-preserving)
     t = time.time()
-    _, counts = oracle.render(osc, oenv, cam, width, height, 0, 1, bounces, flags=oracle.FLAG_PRUNE | oracle.FLAG_ANYHIT_SHADOW,
+    _, counts = oracle.render(osc, oenv, cam, width, height, 0, 1, bounces, flags=oracle.FLAG_ANYHIT_SHADOW,
                               n_threads=cores, fast=True)
     t_counts = time.time() - t
-    # timed baseline: the reference's own traversal (no pruning), sized for roughly 10-20 s
-    spp = int(max(1, min(64, round(15.0 / max(t_counts, 0.05)))))
+    # timed baseline: the reference's own traversal, sized for roughly 15 s (calibrated on 2 spp)
+    t = time.time()
+    oracle.render(osc, oenv, cam, width, height, 0, 2, bounces, flags=0, n_threads=cores, fast=True)
+    t_cal = (time.time() - t) / 2
+    spp = int(max(2, min(256, round(15.0 / max(t_cal, 0.01)))))
     t = time.time()
     _, st = oracle.render(osc, oenv, cam, width, height, 0, spp, bounces, flags=0, n_threads=cores, fast=True)
     dt = time.time() - t
     rays = st["ext_rays"] + st["shadow_rays"]
-    log("cpu_baseline: %d spp in %.2f s on %d threads = %.2f Mrays/s (pruned 1 spp: %.2f s)" % (spp, dt, cores, rays / dt / 1e6, t_counts))
+    log("cpu_baseline: %d spp in %.2f s on %d threads = %.2f Mrays/s (counting pass 1 spp: %.2f s)" % (spp, dt, cores, rays / dt / 1e6, t_counts))
     per_path = algorithmic_bytes(counts) / counts["paths"]
     base = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "house.toml %dx%d, samples 0..%d of every pixel, %d bounces, reference traversal, liboracle_fast.so (-O3, OpenMP dynamic 16x16 tiles)"
@@ -174,7 +178,7 @@ def main():
                 os.makedirs(os.path.dirname(COUNTS_FILE), exist_ok=True)
                 with open(COUNTS_FILE, "w") as f:
                     json.dump({"per_path_algorithmic_bytes": per_path, "counts_1spp": counts,
-                               "source": "oracle, pruned + any-hit traversal, samples 0 of every pixel"}, f, indent=1)
+                               "source": "oracle, unpruned extension rays + any-hit shadow rays, sample 0 of every pixel"}, f, indent=1)
         elif std_cfg and os.path.exists(COUNTS_FILE):
             with open(COUNTS_FILE) as f:
                 per_path = json.load(f)["per_path_algorithmic_bytes"]

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
     uint32_t *stack = reinterpret_cast<uint32_t *>(rt_smem + sc.lds_float4s) + threadIdx.x;
     const uint32_t stride = RT_BLOCK;
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
-    const bool prune = !(P.flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
+    const bool prune = (P.flags & RSRT_FLAG_PRUNE) != 0;
+    const bool anyhit_shadow = !(P.flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
     const uint32_t tile_px = P.tile_w * P.tile_h;
 
     // wave-uniform chunk cursor
@@ -208,8 +209,8 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
         bool occluded = false;
         if (active && want_shadow) {
             Hit sh;
-            if (prune) trace_bvh<true>(S, surf.point, es.direction, true, stack, stride, sh);
-            else trace_bvh<false>(S, surf.point, es.direction, false, stack, stride, sh);
+            if (anyhit_shadow) trace_bvh<true>(S, surf.point, es.direction, prune, stack, stride, sh);
+            else trace_bvh<false>(S, surf.point, es.direction, prune, stack, stride, sh);
             occluded = sh.did_hit();
             n_shadow++;
         }
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
     if (i >= n) return;
     V3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
     V3 d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
-    const bool prune = !(flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
+    const bool prune = (flags & RSRT_FLAG_PRUNE) != 0;
     Hit h;
     if (mode == 0) trace_closest(S, sc, o, d, prune, stack, RT_BLOCK, h);
     else trace_bvh<false>(S, o, d, prune, stack, RT_BLOCK, h);
@@ -825,7 +826,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     if (environment_index >= ctx->envs.size() || !ctx->envs[environment_index].rgba) return fail(ctx, RSRT_ERR_NOT_READY, "environment %u not uploaded", environment_index);
     if (width == 0 || height == 0 || (uint64_t)width * height > 0x7fffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bad resolution %ux%u", width, height);
     if ((uint64_t)sample_begin + sample_count > 0xffffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "sample range overflows u32");
-    if (flags & ~(uint32_t)RSRT_FLAG_REFERENCE_TRAVERSAL) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
+    if (flags & ~(uint32_t)(RSRT_FLAG_REFERENCE_TRAVERSAL | RSRT_FLAG_PRUNE)) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
     rsrt_status st = ensure_accumulator(ctx, width, height);
     if (st) return st;

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_pool_kernel(RenderParams P
     uint32_t *const W = lds32 + wave * L::kWaveLdsDwords; // this wave's hot columns
     uint32_t *const list = W + L::kHotDwords;
     uint32_t *const G = P.cold_state + (size_t)(blockIdx.x * (RT_BLOCK / RT_WAVE) + wave) * L::kWaveColdDwords; // cold columns
-    const bool prune = !(P.flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
+    const bool prune = (P.flags & RSRT_FLAG_PRUNE) != 0;
+    const bool anyhit_shadow = !(P.flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
     const uint32_t tile_px = P.tile_w * P.tile_h;
 
 #define HOT(f, slot) W[(f) * POOL + (slot)]
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_pool_kernel(RenderParams P
                 uint32_t cur = HOT(H_CUR, slot);
                 h.src = SRC_BVH;
                 h.t = HOTF(H_T, slot); h.ref = HOT(H_REF, slot); h.u = HOTF(H_U, slot); h.v = HOTF(H_V, slot);
-                trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && prune, P.trace_budget, cur, h);
+                trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
                 const bool done = cur == RT_END;
                 SETH(H_T, slot, h.t);
                 if (shadow) {

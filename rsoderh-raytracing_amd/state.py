@@ -16,7 +16,8 @@ import numpy as np
 
 from . import _build, types as T
 
-FLAG_REFERENCE_TRAVERSAL = 1
+FLAG_REFERENCE_TRAVERSAL = 1  # shadow query runs to the end too (literal shader.wgsl:1249)
+FLAG_PRUNE = 2                # opt-in t-pruning; NOT exactly result-preserving (include/rsrt.h)
 
 _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "rsrt_upload_scene",
             "rsrt_upload_environment", "rsrt_set_partition", "rsrt_accumulator_resize", "rsrt_accumulator_bind",

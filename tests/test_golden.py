@@ -40,8 +40,6 @@ def test_oracle_ray_batch_matches_golden(name):
     for mode, key in [(0, "hits"), (1, "hits_bvh")]:
         h = oracle.cast_rays(osc, g["ray_o"], g["ray_d"], mode, 0)
         assert np.array_equal(h.view(np.uint32).reshape(-1, 9), g[key])
-        hp = oracle.cast_rays(osc, g["ray_o"], g["ray_d"], mode, oracle.FLAG_PRUNE)
-        assert np.array_equal(hp.view(np.uint32).reshape(-1, 9), g[key])
 
 
 def test_fast_build_is_bit_identical_to_strict_build():

@@ -92,6 +92,24 @@ def test_every_kernel_variant_is_bit_exact(variant, big_env, monkeypatch):
             assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
+def test_opt_in_pruning_stays_within_tolerance(big_env):
+    sc = R.Scene.load_toml(util.scene_path("house"))
+    a, sa = gpu_render(sc, big_env, 160, 90, 0, 8, 8)
+    b, sb = gpu_render(sc, big_env, 160, 90, 0, 8, 8, R.state.FLAG_PRUNE)
+    assert np.all(util.rmse_per_channel(a, b, 8) <= RMSE_TOL)
+    assert (sa["ext_rays"], sa["shadow_rays"]) == (sb["ext_rays"], sb["shadow_rays"])
+
+
+def test_pruning_counterexample_default_flags_are_exact(big_env):
+    """house.toml 1920x1080, sample 149 of pixel (851,477): the path t-pruning gets wrong.  Default
+    flags must give the literal traversal's value there."""
+    sc = R.Scene.load_toml(util.scene_path("house"))
+    lit, _ = gpu_render(sc, big_env, 1920, 1080, 149, 1, 8, R.state.FLAG_REFERENCE_TRAVERSAL)
+    dflt, _ = gpu_render(sc, big_env, 1920, 1080, 149, 1, 8, 0)
+    assert np.array_equal(util.bits(lit), util.bits(dflt))
+    assert list(dflt[477, 851, :3]) == [0.0, 0.0, 0.0]
+
+
 def test_sample_ranges_compose_exactly(big_env):
     """[0,5) then [5,12) into the same accumulator == [0,12) in one call, and == 12 reference frames."""
     sc = R.Scene.load_toml(util.scene_path("house"))
