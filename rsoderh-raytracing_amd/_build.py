@@ -50,6 +50,9 @@ def build_hip(force=False, extra_flags=(), instrument=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     target = HIP_LIB.replace(".so", "_instr.so") if instrument else HIP_LIB
     flags = list(extra_flags) + (["-DRT_INSTRUMENT"] if instrument else [])
+    if os.environ.get("RSRT_WPS"):  # experiment knob: waves per SIMD the pool kernel is compiled for
+        flags.append("-DRT_POOL_WAVES_PER_SIMD=" + os.environ["RSRT_WPS"])
+        force = True
     if os.environ.get("RSRT_LEAFQ"):  # experiment knob: leaves a lane holds before the wave tests primitives
         flags.append("-DRT_LEAFQ=" + os.environ["RSRT_LEAFQ"])
         force = True

@@ -78,7 +78,12 @@ struct SceneView<true> {
     RT_DEV float4 mat(uint32_t i) const { return rt_smem[o_mats + i]; }
     RT_DEV float4 fbs(uint32_t i) const { return rt_smem[o_fbs + i]; }
     // record k of the primitive array named by src (SRC_BVH / SRC_FB_SPHERE / SRC_FB_PLANE)
-    RT_DEV float4 rec(uint32_t src, uint32_t i) const { return rt_smem[(src == SRC_BVH ? o_prims : (src == SRC_FB_SPHERE ? o_fbs : o_fbp)) + i]; }
+    // (written as a sum of one-sided selects: a select BETWEEN two members makes the compiler index this
+    // struct in scratch memory)
+    RT_DEV float4 rec(uint32_t src, uint32_t i) const
+    {
+        return rt_smem[o_prims + (src == SRC_FB_SPHERE ? o_fbs - o_prims : 0u) + (src == SRC_FB_PLANE ? o_fbp - o_prims : 0u) + i];
+    }
     RT_DEV uint32_t esc(uint32_t i) const { return reinterpret_cast<const uint32_t *>(rt_smem + o_esc)[i]; }
 };
 template <>
@@ -89,7 +94,11 @@ struct SceneView<false> {
     RT_DEV float4 trin(uint32_t i) const { return tri_normals[i]; }
     RT_DEV float4 mat(uint32_t i) const { return materials[i]; }
     RT_DEV float4 fbs(uint32_t i) const { return fb_spheres[i]; }
-    RT_DEV float4 rec(uint32_t src, uint32_t i) const { return (src == SRC_BVH ? prims : (src == SRC_FB_SPHERE ? fb_spheres : fb_planes))[i]; }
+    RT_DEV float4 rec(uint32_t src, uint32_t i) const
+    {
+        const ptrdiff_t ds = fb_spheres - prims, dp = fb_planes - prims; // all three live in one allocation
+        return prims[(src == SRC_FB_SPHERE ? ds : 0) + (src == SRC_FB_PLANE ? dp : 0) + (ptrdiff_t)i];
+    }
     RT_DEV uint32_t esc(uint32_t i) const { return reinterpret_cast<const uint32_t *>(escape)[i]; }
 };
 
@@ -148,21 +157,21 @@ RT_DEV float plane_t(V3 o, V3 d, V3 pos, V3 n, V3 rx, V3 rz)
     if (px < 0.0f || 1.0f < px || pz < 0.0f || 1.0f < pz) return RT_NO_HIT;
     return t;
 }
-// cast_ray_triangle, shader.wgsl:409-444
+// cast_ray_triangle, shader.wgsl:409-444.  Predicated instead of early returns (the lanes of a wave
+// run in lockstep anyway): every comparison is the shader's, with its NaN behaviour (a NaN compares
+// false and falls through, exactly as the chain of `if .. return` does).
 RT_DEV float triangle_t(V3 o, V3 d, V3 a, V3 e0, V3 e1, float &u, float &v)
 {
-    V3 op = o - a;
-    V3 p0 = cross(op, e0);
-    V3 p1 = cross(d, e1);
-    float det = dot(e0, p1);
-    float inv = 1.0f / det;
-    if (fabs_(det) < 1.0e-8f) return RT_NO_HIT;
+    const V3 op = o - a;
+    const V3 p0 = cross(op, e0);
+    const V3 p1 = cross(d, e1);
+    const float det = dot(e0, p1);
+    const float inv = 1.0f / det;
     u = dot(op, p1) * inv;
     v = dot(d, p0) * inv;
-    if (u < 0.0f || 1.0f < u) return RT_NO_HIT;
-    if (v < 0.0f || 1.0f < (u + v)) return RT_NO_HIT;
-    float t = dot(e1, p0) * inv;
-    return (t < 1.0e-5f) ? RT_NO_HIT : t;
+    const float t = dot(e1, p0) * inv;
+    const bool reject = (fabs_(det) < 1.0e-8f) | (u < 0.0f) | (1.0f < u) | (v < 0.0f) | (1.0f < (u + v)) | (t < 1.0e-5f);
+    return reject ? RT_NO_HIT : t;
 }
 
 struct Hit {
@@ -629,6 +638,38 @@ RT_DEV void trace_ww(DBG_DECL const View &S, V3 o, V3 d, bool prune, bool anyhit
     }
 }
 
+// ray_intersects_bounds (shader.wgsl:262-293) without branches.  Exactly equivalent:
+//  * t_0 / t_1 start at 0 / INFINITY and are only ever assigned non-NaN values, so
+//    `if (tn > t_0) t_0 = tn` == maxNum(t_0, tn) and `if (tf < t_1) t_1 = tf` == minNum(t_1, tf)
+//    (a NaN tn / tf — 0 * inf for an axis-parallel ray on a box face — is ignored by both forms);
+//  * t_0 only grows and t_1 only shrinks, so "t_0 > t_1 after some axis" == "t_0 > t_1 at the end";
+//  * the near/far swap keeps the shader's compare-and-select (a min/max pair would move a NaN).
+// Returns the slab entry distance through t_entry.
+RT_DEV bool slab_test(float4 n0, float4 n1, V3 o, V3 inv, float &t_entry)
+{
+    float t_0 = 0.0f, t_1 = RT_INFINITY;
+    {
+        const float a = (n0.x - o.x) * inv.x, b = (n1.x - o.x) * inv.x;
+        const bool sw = a > b;
+        t_0 = __builtin_fmaxf(t_0, sw ? b : a);
+        t_1 = __builtin_fminf(t_1, sw ? a : b);
+    }
+    {
+        const float a = (n0.y - o.y) * inv.y, b = (n1.y - o.y) * inv.y;
+        const bool sw = a > b;
+        t_0 = __builtin_fmaxf(t_0, sw ? b : a);
+        t_1 = __builtin_fminf(t_1, sw ? a : b);
+    }
+    {
+        const float a = (n0.z - o.z) * inv.z, b = (n1.z - o.z) * inv.z;
+        const bool sw = a > b;
+        t_0 = __builtin_fmaxf(t_0, sw ? b : a);
+        t_1 = __builtin_fminf(t_1, sw ? a : b);
+    }
+    t_entry = t_0;
+    return !(t_0 > t_1);
+}
+
 // ------------------------------------------------------------------ threaded (stackless) traversal
 // For a fixed sign octant of the ray direction the reference's depth-first order (near child by
 // sign(inv_dir[split_axis]), shader.wgsl:536-547) is a FIXED sequence, so it can be threaded at
@@ -666,45 +707,23 @@ RT_DEV void trace_threaded(DBG_DECL const View &S, uint32_t n_nodes, V3 o, V3 d,
             DBG_ADD(11, 1);
             steps++;
             const float4 n0 = S.node(2u * cur), n1 = S.node(2u * cur + 1u);
-            float t_0 = 0.0f, t_1 = RT_INFINITY;
-            bool inside = true;
-            {
-                float tn = (n0.x - o.x) * inv.x, tf = (n1.x - o.x) * inv.x;
-                if (tn > tf) { float s = tn; tn = tf; tf = s; }
-                if (tn > t_0) t_0 = tn;
-                if (tf < t_1) t_1 = tf;
-                if (t_0 > t_1) inside = false;
-            }
-            if (inside) {
-                float tn = (n0.y - o.y) * inv.y, tf = (n1.y - o.y) * inv.y;
-                if (tn > tf) { float s = tn; tn = tf; tf = s; }
-                if (tn > t_0) t_0 = tn;
-                if (tf < t_1) t_1 = tf;
-                if (t_0 > t_1) inside = false;
-            }
-            if (inside) {
-                float tn = (n0.z - o.z) * inv.z, tf = (n1.z - o.z) * inv.z;
-                if (tn > tf) { float s = tn; tn = tf; tf = s; }
-                if (tn > t_0) t_0 = tn;
-                if (tf < t_1) t_1 = tf;
-                if (t_0 > t_1) inside = false;
-            }
-            if (inside && prune && t_0 > h.t) inside = false;
+            const uint32_t esc = S.esc(ebase + cur); // needed on every path but one: fetch it alongside the node
+            float t_0;
+            bool inside = slab_test(n0, n1, o, inv, t_0);
+            inside = inside & !(prune & (t_0 > h.t));
             const uint32_t idx = as_u(n0.w), la = as_u(n1.w);
             const uint32_t len = la & 0xffffu, axis = la >> 16;
-            if (inside && len == 0u) {
-                cur = ((octant >> axis) & 1u) ? idx : cur + 1u; // near child first
-            } else {
-                if (inside) {
+            const bool descend = inside & (len == 0u);
+            const uint32_t near_child = ((octant >> axis) & 1u) ? idx : cur + 1u; // near child first
+            if (inside & (len != 0u)) {
 #pragma unroll
-                    for (int j = 0; j < RT_LEAFQ; j++) {
-                        qi[j] = (nq == (uint32_t)j) ? idx : qi[j];
-                        ql[j] = (nq == (uint32_t)j) ? len : ql[j];
-                    }
-                    nq++;
+                for (int j = 0; j < RT_LEAFQ; j++) {
+                    qi[j] = (nq == (uint32_t)j) ? idx : qi[j];
+                    ql[j] = (nq == (uint32_t)j) ? len : ql[j];
                 }
-                cur = S.esc(ebase + cur); // subtree (or leaf) done: continue where the stack would pop to
+                nq++;
             }
+            cur = descend ? near_child : esc; // subtree (or leaf) done: continue where the stack would pop to
         }
         // ---- test the held leaves in the order found
         uint32_t j = 0, i = 0;
@@ -716,22 +735,23 @@ RT_DEV void trace_threaded(DBG_DECL const View &S, uint32_t n_nodes, V3 o, V3 d,
             const uint32_t rec = leaf_i + i;
             float u, v;
             const float t = test_record(S, rec, SRC_BVH, o, d, u, v);
-            if (t >= 0.0f && t < h.t) {
-                h.t = t;
-                h.ref = rec;
-                h.u = u;
-                h.v = v;
-                if (anyhit) { cur = RT_END; break; }
-            }
+            const bool better = (t >= 0.0f) & (t < h.t); // strict <: the first of equals keeps winning
+            h.t = better ? t : h.t;
+            h.ref = better ? rec : h.ref;
+            h.u = better ? u : h.u;
+            h.v = better ? v : h.v;
             i++;
-            if (i == leaf_l) {
-                i = 0;
-                j++;
+            const bool next_leaf = i == leaf_l;
+            i = next_leaf ? 0u : i;
+            j += next_leaf ? 1u : 0u;
 #pragma unroll
-                for (int k = 1; k < RT_LEAFQ; k++) {
-                    leaf_i = (j == (uint32_t)k) ? qi[k] : leaf_i;
-                    leaf_l = (j == (uint32_t)k) ? ql[k] : leaf_l;
-                }
+            for (int k = 1; k < RT_LEAFQ; k++) {
+                leaf_i = (next_leaf & (j == (uint32_t)k)) ? qi[k] : leaf_i;
+                leaf_l = (next_leaf & (j == (uint32_t)k)) ? ql[k] : leaf_l;
+            }
+            if (better & anyhit) { // the shadow query only wants to know whether anything is hit
+                cur = RT_END;
+                j = nq;
             }
         }
     }

@@ -53,8 +53,11 @@ RT_DEV uint32_t stage_of_tag(uint32_t tag)
     return tag == TAG_FREE ? ST_GEN : (tag <= TAG_TRACE_SHADOW ? ST_TRACE : (tag == TAG_IDLE ? ST_COUNT : tag - 1u));
 }
 
+#ifndef RT_POOL_WAVES_PER_SIMD
+#define RT_POOL_WAVES_PER_SIMD 4
+#endif
 template <bool LDS, uint32_t POOL>
-__global__ __launch_bounds__(RT_BLOCK) void rt_render_pool_kernel(RenderParams P)
+__global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
 {
     typedef PoolLayout<POOL> L;
     const DevScene &sc = P.scene;
