@@ -915,8 +915,18 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         P.sample_begin = sample_begin + done;
         P.sample_count = std::min(pass_samples, sample_count - done);
         if (max_bounces > 0) {
-            // chunk = one tile x samples_per_chunk samples; enough chunks to balance the tail
-            P.samples_per_chunk = std::max(1u, std::min(P.sample_count, 2048u / tile_px ? 2048u / tile_px : 1u));
+            // chunk = one tile x samples_per_chunk samples.  Up to 8 samples per chunk (2048 paths: the
+            // counter is touched rarely), fewer when the job is small — e.g. one GPU's share of a
+            // partitioned frame — so that every resident wave still gets >= ~32 chunks and the tail,
+            // where waves run out of work at different times, stays a few percent.
+            {
+                const uint64_t waves = (uint64_t)ctx->cus * bpc * (RT_BLOCK / RT_WAVE);
+                const uint64_t want_chunks = 32ull * waves;
+                const uint64_t total_tile_samples = (uint64_t)P.n_owned_tiles * P.sample_count;
+                uint64_t spc = total_tile_samples / std::max<uint64_t>(want_chunks, 1);
+                spc = std::min<uint64_t>(std::max<uint64_t>(spc, 1), std::max<uint32_t>(1u, 2048u / tile_px));
+                P.samples_per_chunk = (uint32_t)std::min<uint64_t>(spc, P.sample_count);
+            }
             P.n_sblocks = (P.sample_count + P.samples_per_chunk - 1) / P.samples_per_chunk;
             const uint64_t n_chunks = (uint64_t)P.n_owned_tiles * P.n_sblocks;
             if (n_chunks > 0xffffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "too many work chunks");

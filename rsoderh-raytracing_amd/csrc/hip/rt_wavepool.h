@@ -91,7 +91,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
     for (int i = 0; i < RT_DBG_N; i++) dbg.c[i] = 0;
 #endif
 
+#ifdef RT_INSTRUMENT
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#define DBG_STAMP(i) do { unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) dbg.c[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define DBG_STAMP(i) do { } while (0)
+#endif
     for (;;) {
+        DBG_STAMP(21); // previous stage's tail is charged below; this resets the clock for the census
         // ---------------- 1. census of the stage tags (each lane looks at its kSlotsPerLane slots)
         uint32_t tags[L::kSlotsPerLane];
         uint32_t count[ST_COUNT] = {0, 0, 0, 0, 0};
@@ -119,6 +126,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
         const bool on = lane < n_run;
         const uint32_t slot = on ? list[lane] : 0u;
         if (lane == 0) { DBG_ADD(best, 1); DBG_ADD(5 + best, n_run); }
+        DBG_STAMP(22); // census + compaction
 
         if (best == ST_GEN) {
             // ---------------- GEN: hand out (pixel, sample) items of the wave's chunk
@@ -323,6 +331,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 (void)point;
             }
         }
+        DBG_STAMP(16 + best); // the stage just run
     }
 #undef HOT
 #undef HOTF

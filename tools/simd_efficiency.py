@@ -24,3 +24,8 @@ print('  trace: outer trips/wave-invocation %.2f' % (c[14] / max(c[1], 1)))
 print('  descend loop: wave trips %.3e, lane trips %.3e -> efficiency %.1f%% of 64 lanes ; nodes/ray %.2f' % (c[10], c[11], 100 * c[11] / max(64 * c[10], 1), c[11] / rays))
 print('  leaf loop   : wave trips %.3e, lane trips %.3e -> efficiency %.1f%% ; prim tests/ray %.2f' % (c[12], c[13], 100 * c[13] / max(64 * c[12], 1), c[13] / rays))
 print('  per TRACE invocation: descend wave trips %.1f, leaf wave trips %.1f' % (c[10] / max(c[1], 1), c[12] / max(c[1], 1)))
+tot = sum(c[16:23])
+if tot:
+    print('  wave-time shares (s_memtime, lane 0): ' + '  '.join('%s %.1f%%' % (n, 100 * c[16 + i] / tot) for i, n in enumerate(names)) +
+          '  census %.1f%%  other %.1f%%' % (100 * c[22] / tot, 100 * c[21] / tot))
+    print('  cycles per invocation: ' + '  '.join('%s %.0f' % (n, c[16 + i] / max(c[i], 1)) for i, n in enumerate(names)) + '  census %.0f' % (c[22] / max(sum(c[0:5]), 1)))
