@@ -838,6 +838,10 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.scene = ctx->scene;
     const Env &env = ctx->envs[environment_index];
     P.env.rgba = env.rgba; P.env.alias = env.alias; P.env.width = env.width; P.env.height = env.height;
+    P.env.wf = (float)env.width;
+    P.env.hf = (float)env.height;
+    P.env.dphi_dtheta = (RT_TWO_PI / (float)env.width) * (RT_PI / (float)env.height);
+    P.env.width_shift = (env.width & (env.width - 1)) == 0 ? (uint32_t)__builtin_ctz(env.width) : 0xffffffffu;
     memcpy(P.cam_pos, camera->pos, 12);
     for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) P.cam_rot[3 * j + k] = camera->rot_transform[j][k];
     P.fov_y = camera->fov_y;

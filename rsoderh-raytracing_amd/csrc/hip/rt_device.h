@@ -61,6 +61,10 @@ struct DevEnv {
     const float4 *rgba;
     const uint4 *alias; // {probability bits, alias_index, pmf bits, pad}
     uint32_t width, height;
+    // uniforms the shader recomputes per call; same f32 operations, done once at upload
+    float wf, hf;           // f32(width), f32(height)
+    float dphi_dtheta;      // (2*PI / f32(width)) * (PI / f32(height)), shader.wgsl:746-748
+    uint32_t width_shift;   // log2(width) when width is a power of two, else 0xffffffff
 };
 
 // Scene accessor: either the LDS image (offsets in float4 units) or global memory.
@@ -354,9 +358,7 @@ RT_DEV float environment_pixel_solid_angle(float v, const DevEnv &e) // :739-749
 {
     float theta = RT_PI * v;
     float sin_t = fmax_(1.0e-6f, rsrt_sinf(theta));
-    float d_phi = RT_TWO_PI / (float)e.width;
-    float d_theta = RT_PI / (float)e.height;
-    return d_phi * d_theta * sin_t;
+    return e.dphi_dtheta * sin_t; // (d_phi * d_theta) * sin_t
 }
 RT_DEV uint32_t clamp_texel(float f, uint32_t n)
 {
@@ -368,7 +370,7 @@ RT_DEV uint32_t clamp_texel(float f, uint32_t n)
 // (src/state.rs:134-142), full-precision f32 weights a*(1-f) + b*f
 RT_DEV V3 sample_env_bilinear(const DevEnv &e, float u, float v)
 {
-    float x = u * (float)e.width - 0.5f, y = v * (float)e.height - 0.5f;
+    float x = u * e.wf - 0.5f, y = v * e.hf - 0.5f;
     float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
     float fx = x - xf, fy = y - yf;
     uint32_t x0 = clamp_texel(xf, e.width), x1 = clamp_texel(xf + 1.0f, e.width);
@@ -382,8 +384,8 @@ RT_DEV V3 sample_env_bilinear(const DevEnv &e, float u, float v)
 }
 RT_DEV float environment_direction_pdf(const DevEnv &e, V3 dir, float u, float v) // :753-769 (uv already computed)
 {
-    uint32_t x = min(f2u(u * (float)e.width), e.width - 1u);
-    uint32_t y = min(f2u(v * (float)e.height), e.height - 1u);
+    uint32_t x = min(f2u(u * e.wf), e.width - 1u);
+    uint32_t y = min(f2u(v * e.hf), e.height - 1u);
     uint32_t index = x + y * e.width;
     float pmf = as_f(e.alias[index].z);
     return pmf / environment_pixel_solid_angle(v, e);
@@ -399,10 +401,12 @@ RT_DEV EnvironmentSample sample_environment(const DevEnv &e, uint32_t &rng) // :
     uint4 entry = e.alias[index];
     float u2 = random_uniform(rng);
     uint32_t pick = (u2 < as_f(entry.x)) ? index : entry.y;
-    uint32_t x = pick % e.width, y = pick / e.width;
+    uint32_t x, y; // pick % width, pick / width
+    if (e.width_shift != 0xffffffffu) { x = pick & (e.width - 1u); y = pick >> e.width_shift; }
+    else { y = pick / e.width; x = pick - y * e.width; }
     float jx = random_uniform(rng), jy = random_uniform(rng);
-    float u = ((float)x + jx) / (float)e.width;
-    float v = ((float)y + jy) / (float)e.height;
+    float u = ((float)x + jx) / e.wf;
+    float v = ((float)y + jy) / e.hf;
     EnvironmentSample s;
     s.direction = equirectangular_uv_to_direction(u, v);
     s.radiance = sample_env_bilinear(e, u, v);
@@ -514,16 +518,45 @@ RT_DEV V3 sample_ggx_visible_half_vector(float sx, float sy, V3 wo, float alpha)
     V3 hs = dx * tx + dy * ty + rsrt_sqrtf(fmax_(0.0f, 1.0f - dx * dx - dy * dy)) * vs;
     return normalize(v3(alpha * hs.x, alpha * hs.y, fmax_(0.0f, hs.z)));
 }
+// bsdf_eval_local and bsdf_pdf_local (shader.wgsl:1053-1114) in one pass: they share h, D and G1(wo);
+// every expression is the one the two separate functions evaluate.
+RT_DEV void bsdf_eval_pdf_local(V3 wo, V3 wi, const BsdfMaterial &m, V3 &f, float &pdf)
+{
+    if (wo.z <= 0.0f || wi.z <= 0.0f) { f = v3(0, 0, 0); pdf = 0.0f; return; }
+    const V3 h = normalize(wo + wi);
+    const float g1_o = g1_ggx(wo.z, m.alpha);
+    {
+        const float ndh = saturate(h.z);
+        const float D = d_ggx(ndh, m.alpha);
+        const float G = g1_o * g1_ggx(wi.z, m.alpha);
+        const V3 F = f_schlick(m.f0, dot(h, wo));
+        const V3 fs = (D * G) / (4.0f * wo.z * wi.z) * F;
+        f = m.kd * RT_INV_PI + fs;
+    }
+    {
+        const float pdf_cos = wi.z / RT_PI;
+        const float wo_dot_h_signed = dot(wo, h);
+        const float wo_dot_h = fabs_(wo_dot_h_signed);
+        float pdf_spec;
+        if (wo_dot_h <= 0.0f) pdf_spec = 0.0f;
+        else {
+            const float hv = (h.z <= 0.0f) ? 0.0f : d_ggx(h.z, m.alpha) * g1_o * fmax_(0.0f, wo_dot_h_signed) / wo.z;
+            pdf_spec = hv / (4.0f * wo_dot_h);
+        }
+        pdf = m.diff_prob * pdf_cos + m.spec_prob * pdf_spec;
+    }
+}
+
 struct BsdfSample {
     V3 dir, scattering;
     float pdf;
 };
-RT_DEV BsdfSample bsdf_sample(V3 ray_dir, V3 n, const BsdfMaterial &m, uint32_t &rng) // :1116-1202
+// `frame` = make_frame(n) and `wo` = to_frame_local(frame, -ray_dir): callers that already have them
+// (the NEE evaluation uses the same two) pass them in; the values are what the shader recomputes.
+RT_DEV BsdfSample bsdf_sample_in_frame(V3 ray_dir, V3 n, const Frame &frame, V3 wo, const BsdfMaterial &m, uint32_t &rng) // :1116-1202
 {
     V3 wo_world = -ray_dir;
     if (dot(n, wo_world) <= 0.0f) return BsdfSample{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
-    Frame frame = make_frame(n);
-    V3 wo = to_frame_local(frame, wo_world);
     if (wo.z <= 0.0f) return BsdfSample{v3(0, 0, 0), v3(0, 1, 0), 0.0f};
     V3 wi;
     float s = random_uniform(rng);
@@ -539,11 +572,17 @@ RT_DEV BsdfSample bsdf_sample(V3 ray_dir, V3 n, const BsdfMaterial &m, uint32_t 
         wi = i - (2.0f * dot(h, i)) * h; // reflect(-wo, h)
         if (wi.z <= 0.0f) return BsdfSample{v3(1, 0, 0), v3(1, 0, 0), 0.0f};
     }
-    V3 scattering = bsdf_eval_local(wo, wi, m);
-    float pdf = bsdf_pdf_local(wo, wi, m);
+    V3 scattering;
+    float pdf;
+    bsdf_eval_pdf_local(wo, wi, m, scattering, pdf);
     V3 wi_world = to_frame_world(frame, wi);
     if (dot(n, wi_world) < 0.0f) return BsdfSample{v3(0, 0, 0), v3(0, 1, 0), 0.0f};
     return BsdfSample{wi_world, scattering, pdf};
+}
+RT_DEV BsdfSample bsdf_sample(V3 ray_dir, V3 n, const BsdfMaterial &m, uint32_t &rng)
+{
+    const Frame frame = make_frame(n);
+    return bsdf_sample_in_frame(ray_dir, n, frame, to_frame_local(frame, -ray_dir), m, rng);
 }
 RT_DEV float power_heuristic(float a, float b) // :1206-1210
 {

@@ -291,16 +291,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 const uint32_t bounce = COLD(C_BOUNCE, slot) + 1u;
                 const uint32_t out = COLD(C_OUT, slot);
                 const BsdfMaterial mat = load_material(S, mat_id);
+                const Frame frame = make_frame(normal); // shader.wgsl:1252 and :1133 build the same frame
+                const V3 wo = to_frame_local(frame, -d);
                 if (cos_nee > 0.0f && !occluded) { // lit: cos > 0, pdf > 0, not occluded
-                    const Frame frame = make_frame(normal);
-                    const V3 wo = to_frame_local(frame, -d);
                     const V3 wi = to_frame_local(frame, edir);
-                    const V3 scattering = bsdf_eval_local(wo, wi, mat);
-                    const float pdf_bsdf = bsdf_pdf_local(wo, wi, mat);
+                    V3 scattering;
+                    float pdf_bsdf;
+                    bsdf_eval_pdf_local(wo, wi, mat, scattering, pdf_bsdf);
                     const float w = power_heuristic(epdf, pdf_bsdf);
                     Lr = Lr + T * w * erad * scattering * cos_nee / epdf;
                 }
-                const BsdfSample bs = bsdf_sample(d, normal, mat, rng);
+                const BsdfSample bs = bsdf_sample_in_frame(d, normal, frame, wo, mat, rng);
                 bool finished = false;
                 if (bs.dir.x == 0.0f && bs.dir.y == 0.0f && bs.dir.z == 0.0f) {
                     Lr = bs.scattering;
