@@ -58,7 +58,7 @@ def cpu_leg(scene, env, width, height, bounces, log):
     t = time.time()
     oracle.render(osc, oenv, cam, width, height, 0, 2, bounces, flags=0, n_threads=cores, fast=True)
     t_cal = (time.time() - t) / 2
-    spp = int(max(2, min(256, round(15.0 / max(t_cal, 0.01)))))
+    spp = int(max(2, min(256, round(20.0 / max(t_cal, 0.01)))))
     t = time.time()
     _, st = oracle.render(osc, oenv, cam, width, height, 0, spp, bounces, flags=0, n_threads=cores, fast=True)
     dt = time.time() - t
@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--scene", default="house")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real thing) or gloo (rehearsal of N > 1 on one GPU)")
     ap.add_argument("--write-counts", action="store_true", help="store the per-path algorithmic bytes under profiles/")
     args = ap.parse_args()
 
@@ -111,10 +112,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the integrator has no CPU path")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()  # == local_rank on a real N-GPU node
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import rsoderh_raytracing_amd as R
     from rsoderh_raytracing_amd import partition
@@ -123,7 +128,7 @@ def main():
     env = R.Environment.synthetic(2048, 1024)
     W, H, spp = args.width, args.height, args.spp
 
-    state = R.State.new(scene, env, W, H, device=local_rank)
+    state = R.State.new(scene, env, W, H, device=device_index)
     state.max_bounces = args.bounces
     state.set_partition(rank, world, partition.TILE_W, partition.TILE_H)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
@@ -135,7 +140,13 @@ def main():
         acc.zero_()
         state.render_range(0, spp, stream=stream.cuda_stream)
         if world > 1:
-            partition.reduce_accumulators(acc)
+            if args.backend == "nccl":
+                partition.reduce_accumulators(acc)  # one RCCL reduce(sum) over xGMI
+            else:  # rehearsal: gloo reduces on the host
+                host = acc.cpu()
+                partition.reduce_accumulators(host)
+                if rank == 0:
+                    acc.copy_(host)
 
     def fence():
         if world > 1:
@@ -155,8 +166,9 @@ def main():
         elapsed = time.perf_counter() - t0
 
     s = state.stats()
-    tot = torch.tensor([float(s["ext_rays"] + s["shadow_rays"]), float(s["paths"])], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    cdev = "cuda" if args.backend == "nccl" else "cpu"
+    tot = torch.tensor([float(s["ext_rays"] + s["shadow_rays"]), float(s["paths"])], dtype=torch.float64, device=cdev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

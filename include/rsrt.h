@@ -126,6 +126,11 @@ rsrt_status rsrt_accumulator_download(rsrt_context *ctx, float *host_rgba, size_
 /* out_texture: mean = sum / sample_total rounded to binary16 (shader.wgsl:1369-1372) */
 rsrt_status rsrt_resolve_mean_f16(rsrt_context *ctx, uint32_t sample_total, uint16_t *host_rgba16f, size_t n_halfs);
 
+/* The display pass (src/shaders/hdr.wgsl `fs_main`, src/hdr.rs:162-200): mean through binary16 ->
+ * ACES fit (negatives -> magenta) -> sRGB 8-bit, as the *Srgb surface stores it.  RGBA8, alpha 255.
+ * Arithmetic published in include/rsrt_tonemap.h. */
+rsrt_status rsrt_display_srgb8(rsrt_context *ctx, uint32_t sample_total, uint8_t *host_rgba8, size_t n_bytes);
+
 /* -- render: State::render's compute pass (state.rs:808-824), batched over samples -----------
  * Adds samples [sample_begin, sample_begin + sample_count) of every owned pixel into the
  * accumulator (alpha := 1), in increasing sample order per pixel, on `hip_stream`

@@ -12,6 +12,10 @@
  *   rsrt_plane_to_uniform    Plane::to_uniform           src/scene.rs:190-201
  *   rsrt_camera_uniform      CameraUniform::new          src/camera.rs:26-28, :111-119
  *   rsrt_alias_table_build   AliasTable::build_by_luminance  src/environments.rs:96-187
+ *   rsrt_load_hdr            image::load_from_memory(..).into_rgb32f() for Radiance .hdr  src/state.rs:119-132
+ *   rsrt_camera_(de)serialize Camera::serialize / deserialize (--state)  src/camera.rs:30-89
+ *   rsrt_display_srgb8_host  hdr.wgsl aces_tone_map + sRGB surface write  src/shaders/hdr.wgsl:3-22
+ *   rsrt_write_png/_pfm      image output (the reference only presents to a window)
  *   rsrt_synth_environment   stand-in for the two HDRIs the checkout lacks (state.rs:119-122;
  *                            .MISSING_LARGE_BLOBS) — deterministic formula, DESIGN.md §env
  */
@@ -72,6 +76,23 @@ int rsrt_alias_table_build(uint32_t width, uint32_t height, const float *rgb, rs
 
 /* Deterministic synthetic equirectangular sky (gradient + sun lobe); rgba_out: w*h*4, alpha 0. */
 int rsrt_synth_environment(uint32_t width, uint32_t height, float *rgba_out);
+
+/* Radiance RGBE (.hdr): rgb_out = malloc'ed width*height*3 f32, rows top to bottom; free with rsrt_free.
+ * value = mantissa * 2^(e-136), (0,0,0) when e == 0 — the `image` 0.25 hdr decoder's rule. */
+int rsrt_load_hdr(const char *path, uint32_t *width, uint32_t *height, float **rgb_out, char *err, size_t err_len);
+void rsrt_free(void *p);
+
+/* 24 bytes [pos.xyz, yaw, pitch, fov_y] little-endian f32 <-> standard base64 (32 chars + NUL).
+ * Deserialize errors carry the reference's text ("Couldn't deserialize camera: binary data (N bytes) not 24 bytes"). */
+void rsrt_camera_serialize(const rsrt_camera_desc *cam, char out[33]);
+int rsrt_camera_deserialize(const char *encoded, rsrt_camera_desc *out, char *err, size_t err_len);
+
+/* Display transform on the CPU (same inline code as the HIP kernel behind rsrt_display_srgb8). */
+void rsrt_display_srgb8_host(const float *sum_rgba, size_t n_pixels, uint32_t sample_total, uint8_t *out_rgba8);
+
+/* Image files: 8-bit RGBA PNG (stored deflate), 32-bit float PFM from a buffer with `stride_floats` per pixel. */
+int rsrt_write_png(const char *path, uint32_t width, uint32_t height, const uint8_t *rgba8);
+int rsrt_write_pfm(const char *path, uint32_t width, uint32_t height, const float *rgb, uint32_t stride_floats);
 
 #ifdef __cplusplus
 }

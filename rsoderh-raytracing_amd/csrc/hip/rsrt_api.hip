@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../../include/rsrt.h"
+#include "../../../include/rsrt_tonemap.h"
 #include "rt_device.h"
 
 #define RT_BLOCK 256
@@ -325,6 +326,18 @@ __global__ void rt_mean_f16_kernel(const float4 *accum, size_t n, float inv_is_u
     float cnt = (float)sample_total; // total_light / f32(sample_count + 1), shader.wgsl:1369
     __half hx = __float2half_rn(a.x / cnt), hy = __float2half_rn(a.y / cnt), hz = __float2half_rn(a.z / cnt), hw = __float2half_rn(1.0f);
     out[i] = make_ushort4(__half_as_ushort(hx), __half_as_ushort(hy), __half_as_ushort(hz), __half_as_ushort(hw));
+}
+
+// hdr.wgsl fs_main + the *Srgb surface write: mean (through binary16) -> ACES -> sRGB 8-bit
+__global__ void rt_display_kernel(const float4 *accum, size_t n, uint32_t sample_total, uchar4 *out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = accum[i];
+    const float sum[3] = {a.x, a.y, a.z};
+    unsigned char rgb[3];
+    rsrt_display_pixel(sum, (float)sample_total, rgb);
+    out[i] = make_uchar4(rgb[0], rgb[1], rgb[2], 255);
 }
 
 // =================================================================== host side
@@ -813,6 +826,23 @@ rsrt_status rsrt_resolve_mean_f16(rsrt_context *ctx, uint32_t sample_total, uint
     if (e == hipSuccess) e = hipMemcpy(host, tmp, n * sizeof(ushort4), hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(ctx, RSRT_ERR_HIP, "resolve_mean_f16: %s", hipGetErrorString(e));
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_display_srgb8(rsrt_context *ctx, uint32_t sample_total, uint8_t *host_rgba8, size_t n_bytes)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
+    const size_t n = (size_t)ctx->acc_w * ctx->acc_h;
+    if (!host_rgba8 || n_bytes != n * 4 || sample_total == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "display_srgb8: expected %zu bytes and sample_total > 0", n * 4);
+    uchar4 *tmp = nullptr;
+    HIP_TRY(ctx, hipMalloc(&tmp, n * sizeof(uchar4)));
+    hipLaunchKernelGGL(rt_display_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->accum, n, sample_total, tmp);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(host_rgba8, tmp, n * sizeof(uchar4), hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(ctx, RSRT_ERR_HIP, "display_srgb8: %s", hipGetErrorString(e));
     return RSRT_OK;
 }
 

@@ -32,6 +32,17 @@ def lib():
         L.rsrt_build_bvh.restype = C.c_int
         L.rsrt_alias_table_build.restype = C.c_int
         L.rsrt_synth_environment.restype = C.c_int
+        L.rsrt_load_hdr.restype = C.c_int
+        L.rsrt_load_hdr.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.rsrt_free.argtypes = [C.c_void_p]
+        L.rsrt_camera_deserialize.restype = C.c_int
+        L.rsrt_camera_deserialize.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.rsrt_camera_serialize.argtypes = [C.c_void_p, C.c_char_p]
+        L.rsrt_write_png.restype = C.c_int
+        L.rsrt_write_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.rsrt_write_pfm.restype = C.c_int
+        L.rsrt_write_pfm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.rsrt_display_srgb8_host.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -172,3 +183,64 @@ class Environment:
     @classmethod
     def synthetic(cls, width=2048, height=1024):
         return cls(synth_environment(width, height))
+
+
+    @classmethod
+    def load_hdr(cls, path):
+        """A Radiance .hdr as the reference's `image::load_from_memory(..).into_rgb32f()` decodes it."""
+        return cls(load_hdr(path))
+
+
+def load_hdr(path):
+    """-> [H, W, 4] float32 RGBA (alpha 0, as src/texture.rs:112-115 writes it)."""
+    w, h, ptr = C.c_uint32(0), C.c_uint32(0), C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = lib().rsrt_load_hdr(os.fsencode(path), C.byref(w), C.byref(h), C.byref(ptr), err, len(err))
+    if rc != 0:
+        raise ValueError("rsrt_load_hdr: " + err.value.decode())
+    try:
+        rgb = np.frombuffer(C.string_at(ptr, w.value * h.value * 12), np.float32).reshape(h.value, w.value, 3)
+    finally:
+        lib().rsrt_free(ptr)
+    rgba = np.zeros((h.value, w.value, 4), np.float32)
+    rgba[..., :3] = rgb
+    return rgba
+
+
+def camera_serialize(camera_desc):
+    """Camera::serialize (src/camera.rs:30-49): the string the `p` key prints and --state takes."""
+    camera_desc = np.ascontiguousarray(camera_desc).view(T.CAMERA_DESC).reshape(1)
+    out = C.create_string_buffer(33)
+    lib().rsrt_camera_serialize(_p(camera_desc), out)
+    return out.value.decode()
+
+
+def camera_deserialize(encoded):
+    """Camera::deserialize (src/camera.rs:51-89); raises ValueError with the reference's message."""
+    out = np.zeros(1, T.CAMERA_DESC)
+    err = C.create_string_buffer(256)
+    if lib().rsrt_camera_deserialize(encoded.encode(), _p(out), err, len(err)) != 0:
+        raise ValueError(err.value.decode())
+    return out
+
+
+def display_srgb8(sum_rgba, sample_total):
+    """hdr.wgsl display pass on the CPU: [H, W, 4] f32 sums -> [H, W, 4] uint8."""
+    sum_rgba = np.ascontiguousarray(sum_rgba, np.float32)
+    out = np.empty(sum_rgba.shape[:2] + (4,), np.uint8)
+    lib().rsrt_display_srgb8_host(_p(sum_rgba), sum_rgba.shape[0] * sum_rgba.shape[1], sample_total, _p(out))
+    return out
+
+
+def write_png(path, rgba8):
+    rgba8 = np.ascontiguousarray(rgba8, np.uint8)
+    assert rgba8.ndim == 3 and rgba8.shape[2] == 4
+    if lib().rsrt_write_png(os.fsencode(path), rgba8.shape[1], rgba8.shape[0], _p(rgba8)) != 0:
+        raise OSError("rsrt_write_png failed: " + str(path))
+
+
+def write_pfm(path, rgb):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    assert rgb.ndim == 3 and rgb.shape[2] >= 3
+    if lib().rsrt_write_pfm(os.fsencode(path), rgb.shape[1], rgb.shape[0], _p(rgb), rgb.shape[2]) != 0:
+        raise OSError("rsrt_write_pfm failed: " + str(path))

@@ -22,7 +22,7 @@ FLAG_PRUNE = 2                # opt-in t-pruning; NOT exactly result-preserving 
 _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "rsrt_upload_scene",
             "rsrt_upload_environment", "rsrt_set_partition", "rsrt_accumulator_resize", "rsrt_accumulator_bind",
             "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_render",
-            "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters"]
+            "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters", "rsrt_display_srgb8"]
 
 
 class RsrtError(RuntimeError):
@@ -68,6 +68,7 @@ def lib():
         L.rsrt_accumulator_clear.argtypes = [C.c_void_p]
         L.rsrt_accumulator_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rsrt_resolve_mean_f16.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+        L.rsrt_display_srgb8.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
         L.rsrt_render.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p]
         L.rsrt_synchronize.argtypes = [C.c_void_p]
         L.rsrt_get_stats.argtypes = [C.c_void_p, C.c_void_p]
@@ -208,6 +209,13 @@ class State:
         out = np.empty((self.height, self.width, 4), np.float16)
         n = sample_total if sample_total is not None else self.sample_count
         self._check(self._L.rsrt_resolve_mean_f16(self._ctx, n, _p(out), out.size), "rsrt_resolve_mean_f16")
+        return out
+
+    def display_srgb8(self, sample_total=None):
+        """What the reference shows on screen: [H, W, 4] uint8 (ACES tonemap of the f16 mean, sRGB encoded)."""
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        n = sample_total if sample_total is not None else self.sample_count
+        self._check(self._L.rsrt_display_srgb8(self._ctx, n, _p(out), out.size), "rsrt_display_srgb8")
         return out
 
     def stats(self):
