@@ -1,4 +1,6 @@
 """In-tree native builds: librsrt_host.so (g++, CPU preprocessing) and librsrt.so (hipcc, gfx950)."""
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -27,6 +29,17 @@ def _deps(subdir):
     return out
 
 
+@contextlib.contextmanager
+def _locked():
+    """Serialises builds between processes (N bench ranks import the package at the same moment)."""
+    with open(os.path.join(PKG, ".build.lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
 def _run(cmd):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
@@ -36,8 +49,11 @@ def _run(cmd):
 
 def build_host(force=False):
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    if force or _newer(HOST_LIB, _deps("host")):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wextra", "-o", HOST_LIB] + srcs)
+    with _locked():
+        if force or _newer(HOST_LIB, _deps("host")):
+            tmp = HOST_LIB + ".tmp%d" % os.getpid()
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wextra", "-o", tmp] + srcs)
+            os.replace(tmp, HOST_LIB)
     return HOST_LIB
 
 
@@ -56,9 +72,12 @@ def build_hip(force=False, extra_flags=(), instrument=False):
     if os.environ.get("RSRT_LEAFQ"):  # experiment knob: leaves a lane holds before the wave tests primitives
         flags.append("-DRT_LEAFQ=" + os.environ["RSRT_LEAFQ"])
         force = True
-    if force or _newer(target, _deps("hip")):
-        _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-              "-fno-fast-math", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", INCLUDE, "-o", target] + flags + srcs)
+    with _locked():
+        if force or _newer(target, _deps("hip")):
+            tmp = target + ".tmp%d" % os.getpid()
+            _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                  "-fno-fast-math", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", INCLUDE, "-o", tmp] + flags + srcs)
+            os.replace(tmp, target)
     return target
 
 
