@@ -28,6 +28,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 COUNTS_FILE = os.path.join(ROOT, "profiles", "algo_counts_house_1080p_8b.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic_house_1080p_8b.json")  # rocprofv3 PMC, tools/profile.sh
 
 
 def algorithmic_bytes(st):
@@ -200,8 +201,13 @@ def main():
             owned_pixels = int(partition.owned_mask(W, H, rank, world).sum())
             algo = per_path * paths_per_launch + 16.0 * owned_pixels
             achieved = algo / (trace_ms_per_launch * 1e-3) / 1e9
+            traffic = None  # PMC counters cannot be read from inside this process: committed rocprofv3 measurement
+            if std_cfg and world == 1 and spp == 256 and os.path.exists(TRAFFIC_FILE):
+                with open(TRAFFIC_FILE) as f:
+                    tj = json.load(f)
+                traffic = (tj.get("fetch_bytes_per_launch") or 0) + (tj.get("write_bytes_per_launch") or 0)
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "rt_render_kernel", "launch_ms": trace_ms_per_launch,
+                        "traffic": traffic, "kernel": "rt_render_pool_kernel", "launch_ms": trace_ms_per_launch,
                         "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_per_path": per_path,
                         "sample_buffer_bytes_per_launch": 24.0 * paths_per_launch,
                         "note": "working set (5.5 KB scene in LDS + 64 MiB environment, MALL-resident) is cache-resident by "

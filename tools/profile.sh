@@ -16,6 +16,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_IN
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc$i" -- $BENCH --steps 1 --warmup 0 > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err" || echo "pmc set $i failed: $set"
 done
 python3 $R/tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+python3 $R/tools/summarize_traffic.py "$OUT" "$OUT/hbm_traffic_house_1080p_8b.json" > /dev/null 2>&1
 cat "$OUT/summary.txt"
 # keep the merge small
 find "$OUT" -name "*.csv" -size +2M -delete
