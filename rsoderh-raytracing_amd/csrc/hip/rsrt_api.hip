@@ -381,15 +381,15 @@ struct rsrt_context {
     unsigned long long *dev_stats = nullptr;
     // stats
     rsrt_stats stats{};
-    bool stats_pending = false;
     struct PassEvents { hipEvent_t begin, traced, end; };
     std::vector<PassEvents> pending_events;
-    double trace_ms_acc = 0, resolve_ms_acc = 0;
+    double cum_trace_ms = 0, cum_resolve_ms = 0, base_trace_ms = 0, base_resolve_ms = 0;
+    unsigned long long base_counts[3] = {0, 0, 0};
+    uint32_t cum_launches = 0, base_launches = 0;
     std::vector<hipEvent_t> event_pool;
     int blocks_per_cu[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // [lds][kernel variant]
     int kernel_variant = 2; // 0 megakernel, 1..3 wave-pool with 64/128/192 slots per wave
     uint32_t trace_budget = 24; // traversal steps per TRACE invocation before a ray is re-queued
-    uint32_t launches_pending = 0;
     unsigned long long debug_words[32] = {0};
 };
 
@@ -489,41 +489,52 @@ hipEvent_t get_event(rsrt_context *ctx)
     return e;
 }
 
-// Folds finished launches' HIP-event times and device counters into ctx->stats.
-rsrt_status collect_stats(rsrt_context *ctx)
+// Folds finished launches' HIP-event times into the cumulative totals (may run at any time, e.g. to
+// bound the event pool) — it never touches the "since the previous rsrt_get_stats" window.
+rsrt_status collect_events(rsrt_context *ctx)
 {
-    if (!ctx->stats_pending) return RSRT_OK;
+    if (ctx->pending_events.empty()) return RSRT_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    double ms = 0, trace_ms = 0, resolve_ms = 0;
     for (auto &pe : ctx->pending_events) {
         float t1 = 0, t2 = 0;
         HIP_TRY(ctx, hipEventSynchronize(pe.end));
         HIP_TRY(ctx, hipEventElapsedTime(&t1, pe.begin, pe.traced));
         HIP_TRY(ctx, hipEventElapsedTime(&t2, pe.traced, pe.end));
-        trace_ms += t1;
-        resolve_ms += t2;
-        ms += t1 + t2;
+        ctx->cum_trace_ms += t1;
+        ctx->cum_resolve_ms += t2;
         ctx->event_pool.push_back(pe.begin);
         ctx->event_pool.push_back(pe.traced);
         ctx->event_pool.push_back(pe.end);
     }
     ctx->pending_events.clear();
-    ctx->stats.trace_kernel_ms = trace_ms;
-    ctx->stats.resolve_kernel_ms = resolve_ms;
+    return RSRT_OK;
+}
+
+// rsrt_get_stats: cumulative totals now, and the difference to the totals at the previous call.
+rsrt_status collect_stats(rsrt_context *ctx)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    rsrt_status st = collect_events(ctx);
+    if (st) return st;
     unsigned long long c[RT_STATS_WORDS] = {0}; // device counters are cumulative
     HIP_TRY(ctx, hipMemcpy(c, ctx->dev_stats, sizeof c, hipMemcpyDeviceToHost));
-    ctx->stats.paths = c[0] - ctx->stats.total_paths;
-    ctx->stats.ext_rays = c[1] - ctx->stats.total_ext_rays;
-    ctx->stats.shadow_rays = c[2] - ctx->stats.total_shadow_rays;
-    ctx->stats.kernel_ms = ms;
-    ctx->stats.total_paths = c[0];
-    ctx->stats.total_ext_rays = c[1];
-    ctx->stats.total_shadow_rays = c[2];
-    ctx->stats.total_kernel_ms += ms;
-    ctx->stats.launches = ctx->launches_pending;
-    ctx->launches_pending = 0;
+    rsrt_stats &s = ctx->stats;
+    s.paths = c[0] - ctx->base_counts[0];
+    s.ext_rays = c[1] - ctx->base_counts[1];
+    s.shadow_rays = c[2] - ctx->base_counts[2];
+    s.trace_kernel_ms = ctx->cum_trace_ms - ctx->base_trace_ms;
+    s.resolve_kernel_ms = ctx->cum_resolve_ms - ctx->base_resolve_ms;
+    s.kernel_ms = s.trace_kernel_ms + s.resolve_kernel_ms;
+    s.launches = ctx->cum_launches - ctx->base_launches;
+    s.total_paths = c[0];
+    s.total_ext_rays = c[1];
+    s.total_shadow_rays = c[2];
+    s.total_kernel_ms = ctx->cum_trace_ms + ctx->cum_resolve_ms;
+    for (int i = 0; i < 3; i++) ctx->base_counts[i] = c[i];
+    ctx->base_trace_ms = ctx->cum_trace_ms;
+    ctx->base_resolve_ms = ctx->cum_resolve_ms;
+    ctx->base_launches = ctx->cum_launches;
     memcpy(ctx->debug_words, c + 3, sizeof ctx->debug_words);
-    ctx->stats_pending = false;
     return RSRT_OK;
 }
 
@@ -860,7 +871,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
     rsrt_status st = ensure_accumulator(ctx, width, height);
     if (st) return st;
-    if (ctx->pending_events.size() >= 32) { st = collect_stats(ctx); if (st) return st; } // bounds the event pool
+    if (ctx->pending_events.size() >= 32) { st = collect_events(ctx); if (st) return st; } // bounds the event pool
     if (sample_count == 0) return RSRT_OK;
 
     RenderParams P;
@@ -971,17 +982,16 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
             grid = std::max(grid, 1u);
             void *kargs[] = {&P};
             HIP_TRY(ctx, hipLaunchKernel(kfn, dim3(grid), dim3(RT_BLOCK), kargs, smem, stream));
-            ctx->launches_pending++;
+            ctx->cum_launches++;
         } else {
             HIP_TRY(ctx, hipMemsetAsync(ctx->sample_buf, 0, per_sample * P.sample_count, stream));
         }
         HIP_TRY(ctx, hipEventRecord(pe.traced, stream));
         hipLaunchKernelGGL(rt_resolve_kernel, dim3((P.n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, P, ctx->accum);
         HIP_TRY(ctx, hipGetLastError());
-        ctx->launches_pending++;
+        ctx->cum_launches++;
         HIP_TRY(ctx, hipEventRecord(pe.end, stream));
         ctx->pending_events.push_back(pe);
-        ctx->stats_pending = true;
         last_end = pe.end;
     }
     if (stream != ctx->stream && last_end) {
@@ -1013,7 +1023,6 @@ rsrt_status rsrt_get_debug_counters(rsrt_context *ctx, uint64_t out[32])
 {
     if (!ctx || !out) return RSRT_ERR_INVALID_ARGUMENT;
     DeviceGuard g(ctx->device);
-    ctx->stats_pending = true; // force a read-back of the device words
     rsrt_status st = collect_stats(ctx);
     if (st) return st;
     for (int i = 0; i < 32; i++) out[i] = ctx->debug_words[i];

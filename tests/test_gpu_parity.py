@@ -173,6 +173,28 @@ def test_full_size_properties(big_env):
     assert np.array_equal(util.bits(a), util.bits(ref))
 
 
+def test_stats_window_survives_many_small_calls(big_env):
+    """40 one-sample frames (more than the library's event pool) must add up to one 40-sample call."""
+    sc = R.Scene.load_toml(util.scene_path("default"))
+    st = R.State.new(sc, big_env, 96, 64)
+    st.render_range(0, 40)
+    one = st.stats()
+    st.clear()
+    for k in range(40):
+        st.render_range(k, 1)
+    many = st.stats()
+    img_many = st.download()
+    st.clear()
+    st.render_range(0, 40)
+    img_one = st.download()
+    st.close()
+    for key in ("paths", "ext_rays", "shadow_rays"):
+        assert one[key] == many[key], key
+    assert many["launches"] == 80 and one["launches"] == 2
+    assert many["kernel_ms"] > 0 and abs(many["kernel_ms"] - (many["trace_kernel_ms"] + many["resolve_kernel_ms"])) < 1e-6
+    assert np.array_equal(util.bits(img_one), util.bits(img_many))
+
+
 def test_mean_f16_and_alpha(big_env):
     sc = R.Scene.load_toml(util.scene_path("default"))
     st = R.State.new(sc, big_env, 64, 40)
