@@ -145,7 +145,8 @@ rsrt_status rsrt_get_stats(rsrt_context *ctx, rsrt_stats *out);
 /* -- ray-query probe: cast_ray / cast_ray_bvh for a batch of rays (shader.wgsl:469-601) -------
  * Exists for parity tests of traversal + intersection without the RNG: out records are
  * {did_hit u32, distance f32, hit_point 3xf32, normal 3xf32, material_id u32} = 36 bytes.
- * mode 0 = cast_ray (BVH then brute-force fallback), 1 = cast_ray_bvh. Host pointers. */
+ * mode 0 = cast_ray (BVH then brute-force fallback), 1 = cast_ray_bvh — both through the production
+ * kernel's threaded traversal; mode | 2 = the same through the first kernel's stack traversal. Host pointers. */
 typedef struct rsrt_hit {
     uint32_t did_hit;
     float distance;

@@ -301,8 +301,29 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
     V3 d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
     const bool prune = (flags & RSRT_FLAG_PRUNE) != 0;
     Hit h;
-    if (mode == 0) trace_closest(S, sc, o, d, prune, stack, RT_BLOCK, h);
-    else trace_bvh<false>(S, o, d, prune, stack, RT_BLOCK, h);
+    if (mode & 2u) { // the stack traversal of the first kernel
+        if ((mode & 1u) == 0) trace_closest(S, sc, o, d, prune, stack, RT_BLOCK, h);
+        else trace_bvh<false>(S, o, d, prune, stack, RT_BLOCK, h);
+    } else { // the threaded traversal of the production kernel
+        uint32_t cur = 0;
+        h.t = RT_INFINITY; h.ref = 0; h.src = SRC_BVH; h.u = h.v = 0.0f;
+#ifdef RT_INSTRUMENT
+        DbgCounters dbg;
+#endif
+        trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, false, 0xffffffffu, cur, h);
+        if ((mode & 1u) == 0 && !h.did_hit()) { // cast_ray's brute-force fallback
+            for (uint32_t k = 0; k < sc.n_spheres; k++) {
+                float u, v;
+                float t = test_record(S, k, SRC_FB_SPHERE, o, d, u, v);
+                if (t >= 0.0f && t < h.t) { h.t = t; h.ref = k; h.src = SRC_FB_SPHERE; }
+            }
+            for (uint32_t k = 0; k < sc.n_planes; k++) {
+                float u, v;
+                float t = test_record(S, k, SRC_FB_PLANE, o, d, u, v);
+                if (t >= 0.0f && t < h.t) { h.t = t; h.ref = k; h.src = SRC_FB_PLANE; }
+            }
+        }
+    }
     rsrt_hit r;
     memset(&r, 0, sizeof r);
     if (h.did_hit()) {
@@ -312,7 +333,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
         r.hit_point[0] = s.point.x; r.hit_point[1] = s.point.y; r.hit_point[2] = s.point.z;
         r.normal[0] = s.normal.x; r.normal[1] = s.normal.y; r.normal[2] = s.normal.z;
         r.material_id = s.material_id;
-    } else if (mode == 0) {
+    } else if ((mode & 1u) == 0) {
         r.distance = RT_INFINITY; // cast_ray returns its `result` initialiser on a total miss (shader.wgsl:568-574, :600)
     }
     out[i] = r;
@@ -1036,7 +1057,7 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
     DeviceGuard g(ctx->device);
     if (!ctx->scene_ready) return fail(ctx, RSRT_ERR_NOT_READY, "no scene uploaded");
     if (n == 0) return RSRT_OK;
-    if (!origins || !dirs || !out || mode > 1) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: bad arguments");
+    if (!origins || !dirs || !out || mode > 3) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: bad arguments");
     float *d_o = nullptr, *d_d = nullptr;
     rsrt_hit *d_h = nullptr;
     hipError_t e = hipMalloc(&d_o, (size_t)n * 12);

@@ -59,7 +59,7 @@ def test_matches_golden_images_bit_exact(name):
 def test_ray_batch_matches_golden_bit_exact(name):
     g = golden(name)
     st = R.State.new(R.Scene.load_toml(util.scene_path(name)), golden_env(), 16, 16)
-    for mode, key in [(0, "hits"), (1, "hits_bvh")]:
+    for mode, key in [(0, "hits"), (1, "hits_bvh"), (2, "hits"), (3, "hits_bvh")]:
         for flags in (0, R.state.FLAG_REFERENCE_TRAVERSAL):
             h = st.cast_rays(g["ray_o"], g["ray_d"], mode, flags)
             assert np.array_equal(np.ascontiguousarray(h).view(np.uint32).reshape(-1, 9), g[key]), (key, flags)
@@ -90,6 +90,91 @@ def test_every_kernel_variant_is_bit_exact(variant, big_env, monkeypatch):
             img, st = gpu_render(sc, big_env, w, h, 0, spp, mb, flags)
             assert np.array_equal(util.bits(img), util.bits(ref)), (name, variant, flags)
             assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+
+
+def _axis_parallel_rays(scene, rng, n=4096):
+    """Rays with exactly zero direction components (inv_dir = +-inf) starting ON node / primitive bounds,
+    so that (bound - origin) * inv_dir hits 0 * inf = NaN in the slab test — the case the branch-free
+    slab test must treat exactly like the shader's compare chain."""
+    nodes = scene.bvh_nodes
+    lo, hi = nodes["bounds_min"], nodes["bounds_max"]
+    o = np.zeros((n, 3), np.float32)
+    d = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        k = rng.integers(0, len(nodes))
+        corner = np.where(rng.integers(0, 2, 3) == 1, hi[k], lo[k]).astype(np.float32)
+        mode = i % 4
+        p = corner.copy()
+        if mode >= 1:  # move off the corner along some axes, staying on at least one face plane
+            ax = rng.integers(0, 3)
+            p[ax] += np.float32(rng.normal())
+        if mode == 3:
+            p[(ax + 1) % 3] += np.float32(rng.normal() * 0.5)
+        o[i] = p
+        axis = rng.integers(0, 3)
+        if i % 3 == 0:      # one non-zero component
+            d[i, axis] = rng.choice([-1.0, 1.0])
+        elif i % 3 == 1:    # two non-zero components
+            v = rng.normal(size=2)
+            v /= np.linalg.norm(v)
+            d[i, (axis + 1) % 3], d[i, (axis + 2) % 3] = v
+        else:               # negative zero in one component
+            v = rng.normal(size=3)
+            v[axis] = -0.0
+            d[i] = v / np.linalg.norm(v)
+    return o, d
+
+
+@pytest.mark.parametrize("name", ["house", "default", "suzanne"])
+def test_axis_parallel_rays_on_box_faces_bit_exact(name):
+    sc = R.Scene.load_toml(util.scene_path(name))
+    osc = util.oracle_scene(sc)
+    o, d = _axis_parallel_rays(sc, np.random.default_rng(11))
+    st = R.State.new(sc, golden_env(), 16, 16)
+    for mode in (0, 1, 2, 3):  # threaded traversal (production kernel), then the stack traversal
+        ref = oracle.cast_rays(osc, o, d, mode & 1, 0)
+        got = st.cast_rays(o, d, mode, 0)
+        a = np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9)
+        b = ref.view(np.uint32).reshape(-1, 9)
+        assert np.array_equal(a, b), (name, mode, int((a != b).any(axis=1).sum()))
+    st.close()
+
+
+def test_random_scenes_bit_exact(big_env):
+    """Random spheres / planes / triangles (degenerate and coincident ones included), random cameras."""
+    from rsoderh_raytracing_amd import host, types as T
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        ns, npl, nt = int(rng.integers(0, 8)), int(rng.integers(0, 3)), int(rng.integers(1, 40))
+        mats = np.zeros(4, T.MATERIAL)
+        mats["color"] = rng.uniform(0.1, 1, (4, 3))
+        mats["roughness"] = [1.0, 0.3, 0.0, 0.6]
+        mats["metallic"] = [0.0, 1.0, 1.0, 0.5]
+        mats["emission"] = [[0, 0, 0], [0, 0, 0], [0, 0, 0], [0.5, 0.2, 0.1]]
+        sph = np.zeros(ns, T.SPHERE)
+        sph["pos"], sph["radius"], sph["material_id"] = rng.uniform(-3, 3, (ns, 3)), rng.uniform(0.2, 1.0, ns), rng.integers(0, 4, ns)
+        pls = np.zeros(npl, T.PLANE_DESC)
+        pls["pos"], pls["forward"], pls["right"] = rng.uniform(-4, 0, (npl, 3)), rng.uniform(-6, 6, (npl, 3)), rng.uniform(-6, 6, (npl, 3))
+        pls["material_id"] = rng.integers(0, 4, npl)
+        verts = np.zeros(3 * nt, T.VEC3)
+        verts["v"] = np.round(rng.uniform(-3, 3, (3 * nt, 3)) * 4) / 4  # coarse grid: shared edges, coplanar faces
+        norms = np.zeros(3 * nt, T.VEC3)
+        nn = rng.normal(size=(3 * nt, 3))
+        norms["v"] = nn / np.linalg.norm(nn, axis=1, keepdims=True)
+        tri = np.zeros(nt, T.TRIANGLE)
+        tri["vertex_0"], tri["vertex_1"], tri["vertex_2"] = np.arange(nt) * 3, np.arange(nt) * 3 + 1, np.arange(nt) * 3 + 2
+        tri["normal_0"], tri["normal_1"], tri["normal_2"] = tri["vertex_0"], tri["vertex_1"], tri["vertex_2"]
+        tri["material_id"] = rng.integers(0, 4, nt)
+        if trial == 0:  # a degenerate (zero-area) triangle and a duplicate one
+            verts["v"][0:3] = verts["v"][0]
+            verts["v"][3:6] = verts["v"][6:9]
+        cam = host.make_camera_desc(rng.uniform(-1, 1, 3) + [0, 1, 5], yaw=rng.uniform(-0.3, 0.3), pitch=rng.uniform(-0.3, 0.1), fov_y=1.2)
+        sc = R.Scene(mats, sph, pls, verts, norms, tri, cam)
+        ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 80, 48, 0, 4, 6)
+        img, st = gpu_render(sc, big_env, 80, 48, 0, 4, 6)
+        same = util.bits(img) == util.bits(ref)
+        assert same.all(), (trial, int((~same).any(axis=2).sum()))
+        assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
 def test_opt_in_pruning_stays_within_tolerance(big_env):
