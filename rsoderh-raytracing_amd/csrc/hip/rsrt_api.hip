@@ -43,6 +43,7 @@ struct RenderParams {
     uint32_t max_bounces, flags;
     uint32_t tile_w, tile_h, tiles_x, n_tiles, rank, world, n_owned_tiles;
     uint32_t samples_per_chunk, n_sblocks, n_chunks;
+    uint32_t chunk_px, n_subtiles; // a chunk covers chunk_px consecutive pixels of a tile (tile_px / n_subtiles)
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
     uint32_t trace_budget;
     uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
     const uint32_t tile_px = P.tile_w * P.tile_h;
 
     // wave-uniform chunk cursor
-    uint32_t chunk_next = 0, chunk_left = 0, chunk_tile_slot0 = 0, chunk_tx0 = 0, chunk_ty0 = 0, chunk_s0 = 0;
+    uint32_t chunk_next = 0, chunk_left = 0, chunk_tile_slot0 = 0, chunk_tx0 = 0, chunk_ty0 = 0, chunk_s0 = 0, chunk_p0 = 0;
     bool exhausted = false;
 
     PathState ps;
@@ -145,22 +146,24 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
                 if (lane == (uint32_t)__builtin_ctzll(need)) c = atomicAdd(P.work_counter, 1u);
                 c = __builtin_amdgcn_readlane((int)c, __builtin_ctzll(need));
                 if (c >= P.n_chunks) { exhausted = true; break; }
-                uint32_t j = c / P.n_sblocks, b = c % P.n_sblocks; // owned-tile ordinal, sample block
+                const uint32_t q = c % P.n_subtiles, cb = c / P.n_subtiles; // sub-tile, then (tile, sample block)
+                uint32_t j = cb / P.n_sblocks, b = cb % P.n_sblocks; // owned-tile ordinal, sample block
                 uint32_t t = j * P.world + P.rank;
                 chunk_tx0 = (t % P.tiles_x) * P.tile_w;
                 chunk_ty0 = (t / P.tiles_x) * P.tile_h;
                 chunk_tile_slot0 = j * tile_px;
                 chunk_s0 = b * P.samples_per_chunk;
                 uint32_t ns = min(P.samples_per_chunk, P.sample_count - chunk_s0);
+                chunk_p0 = q * P.chunk_px;
                 chunk_next = 0;
-                chunk_left = ns * tile_px;
+                chunk_left = ns * P.chunk_px;
             }
             uint32_t n_need = (uint32_t)__popcll(need);
             uint32_t take = min(n_need, chunk_left);
             uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
             if (!active && rank < take) {
                 uint32_t item = chunk_next + rank;
-                uint32_t k = item / tile_px, p = item % tile_px;
+                uint32_t k = item / P.chunk_px, p = chunk_p0 + item % P.chunk_px;
                 uint32_t px = chunk_tx0 + p % P.tile_w, py = chunk_ty0 + p / P.tile_w;
                 if (px < P.width && py < P.height) {
                     uint32_t srel = chunk_s0 + k;
@@ -992,9 +995,16 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
                 uint64_t spc = total_tile_samples / std::max<uint64_t>(want_chunks, 1);
                 spc = std::min<uint64_t>(std::max<uint64_t>(spc, 1), std::max<uint32_t>(1u, 2048u / tile_px));
                 P.samples_per_chunk = (uint32_t)std::min<uint64_t>(spc, P.sample_count);
+                // very small jobs (one sample per call, the reference's interactive mode): split tiles too,
+                // down to one wave's worth of pixels per chunk
+                P.n_subtiles = 1;
+                while (P.samples_per_chunk == 1 && total_tile_samples * P.n_subtiles < want_chunks && tile_px / (P.n_subtiles * 2) >= RT_WAVE &&
+                       tile_px % (P.n_subtiles * 2) == 0)
+                    P.n_subtiles *= 2;
+                P.chunk_px = tile_px / P.n_subtiles;
             }
             P.n_sblocks = (P.sample_count + P.samples_per_chunk - 1) / P.samples_per_chunk;
-            const uint64_t n_chunks = (uint64_t)P.n_owned_tiles * P.n_sblocks;
+            const uint64_t n_chunks = (uint64_t)P.n_owned_tiles * P.n_sblocks * P.n_subtiles;
             if (n_chunks > 0xffffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "too many work chunks");
             P.n_chunks = (uint32_t)n_chunks;
             HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, sizeof(unsigned int), stream));

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
     for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
         if (lane + 64u * k < POOL) HOT(H_TAG, lane + 64u * k) = TAG_FREE;
 
-    uint32_t chunk_next = 0, chunk_left = 0, chunk_tile_slot0 = 0, chunk_tx0 = 0, chunk_ty0 = 0, chunk_s0 = 0;
+    uint32_t chunk_next = 0, chunk_left = 0, chunk_tile_slot0 = 0, chunk_tx0 = 0, chunk_ty0 = 0, chunk_s0 = 0, chunk_p0 = 0;
     bool exhausted = false;
     unsigned long long n_paths = 0, n_ext = 0, n_shadow = 0;
 #ifdef RT_INSTRUMENT
@@ -137,19 +137,21 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                     if (lane == 0) c = atomicAdd(P.work_counter, 1u);
                     c = __builtin_amdgcn_readfirstlane((int)c);
                     if (c >= P.n_chunks) { exhausted = true; break; }
-                    const uint32_t j = c / P.n_sblocks, b = c % P.n_sblocks;
+                    const uint32_t q = c % P.n_subtiles, cb = c / P.n_subtiles; // sub-tile, then (tile, sample block)
+                    const uint32_t j = cb / P.n_sblocks, b = cb % P.n_sblocks;
                     const uint32_t t = j * P.world + P.rank;
                     chunk_tx0 = (t % P.tiles_x) * P.tile_w;
                     chunk_ty0 = (t / P.tiles_x) * P.tile_h;
                     chunk_tile_slot0 = j * tile_px;
                     chunk_s0 = b * P.samples_per_chunk;
+                    chunk_p0 = q * P.chunk_px;
                     chunk_next = 0;
-                    chunk_left = min(P.samples_per_chunk, P.sample_count - chunk_s0) * tile_px;
+                    chunk_left = min(P.samples_per_chunk, P.sample_count - chunk_s0) * P.chunk_px;
                 }
                 const uint32_t take = min(n_run - given, chunk_left);
                 if (on && lane >= given && lane < given + take) {
                     const uint32_t item = chunk_next + (lane - given);
-                    const uint32_t ks = item / tile_px, p = item % tile_px;
+                    const uint32_t ks = item / P.chunk_px, p = chunk_p0 + item % P.chunk_px;
                     const uint32_t px = chunk_tx0 + p % P.tile_w, py = chunk_ty0 + p / P.tile_w;
                     if (px < P.width && py < P.height) {
                         const uint32_t srel = chunk_s0 + ks;
