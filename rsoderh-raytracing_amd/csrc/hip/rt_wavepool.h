@@ -14,10 +14,11 @@
 //
 // Where the state lives (measured: run time scales ~linearly with resident waves, and LDS is what
 // limits them): the HOT columns — what the traversal loop touches: ray, traversal cursor, best hit,
-// tag — are in LDS, 12 dwords per slot; the COLD columns — throughput, radiance, RNG, NEE carry,
-// shading normal ... only read/written by the shading stages — are in a global-memory arena that
-// stays L2-resident (21 dwords per slot, one contiguous column per field and wave, so a stage's
-// accesses coalesce).  POOL = 128 then costs 6.4 KB of LDS per wave: 16 waves per CU.
+// tag — are in LDS, 9 dwords per slot; the COLD columns — throughput, radiance, RNG, NEE carry,
+// shading normal, the best hit's record / barycentrics ... only read/written by the shading stages
+// (and once per improved hit) — are in a global-memory arena (25 dwords per slot, one contiguous
+// column per field and wave, so a stage's accesses coalesce).  POOL = 192 then costs 7.2 KB of LDS
+// per wave: 16 waves per CU, with 3 slots per lane to pick a full stage from.
 //
 // Stages: GEN (take the next (pixel, sample) of the wave's chunk, build the camera ray)
 //         TRACE (extension rays: closest hit; NEE shadow rays: any hit — one shared, resumable loop)
@@ -27,12 +28,13 @@
 #pragma once
 #include "rt_device.h"
 
-enum HotField { H_OX, H_OY, H_OZ, H_DX, H_DY, H_DZ, H_CUR, H_T, H_REF, H_U, H_V, H_TAG, H_COUNT };
+enum HotField { H_OX, H_OY, H_OZ, H_DX, H_DY, H_DZ, H_CUR, H_T, H_TAG, H_COUNT };
 enum ColdField {
     C_TX, C_TY, C_TZ, C_LX, C_LY, C_LZ, C_LASTPDF, C_RNG, C_BOUNCE, C_OUT,
     C_WX, C_WY, C_WZ,             // direction the path arrived with at the current hit (wo = -w)
     C_NX, C_NY, C_NZ, C_MAT,      // shading normal and material of the current hit
     C_ERX, C_ERY, C_ERZ, C_EPDF, C_COS, // NEE sample: radiance, pdf, cos (0 = no contribution)
+    C_REF, C_U, C_V,              // best hit of the extension ray: record, barycentrics (rewritten only when a TRACE call improves it)
     C_COUNT
 };
 enum PoolTag { TAG_FREE = 0, TAG_TRACE_EXT = 1, TAG_TRACE_SHADOW = 2, TAG_MISS = 3, TAG_SHADE = 4, TAG_BSDF = 5, TAG_IDLE = 6 };
@@ -191,7 +193,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 Hit h;
                 uint32_t cur = HOT(H_CUR, slot);
                 h.src = SRC_BVH;
-                h.t = HOTF(H_T, slot); h.ref = HOT(H_REF, slot); h.u = HOTF(H_U, slot); h.v = HOTF(H_V, slot);
+                h.t = HOTF(H_T, slot); h.ref = 0; h.u = h.v = 0.0f; // ref/u/v of an earlier call stay in the cold columns unless beaten
+                const float t_in = h.t;
                 trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
                 const bool done = cur == RT_END;
                 SETH(H_T, slot, h.t);
@@ -199,9 +202,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                     if (done) { n_shadow++; HOT(H_TAG, slot) = TAG_BSDF; } // H_T < INFINITY <=> occluded
                     else HOT(H_CUR, slot) = cur;
                 } else {
-                    HOT(H_REF, slot) = h.ref;
-                    SETH(H_U, slot, h.u);
-                    SETH(H_V, slot, h.v);
+                    if (h.t < t_in) { // this call found a closer hit
+                        COLD(C_REF, slot) = h.ref;
+                        SETC(C_U, slot, h.u);
+                        SETC(C_V, slot, h.v);
+                    }
                     if (done) { n_ext++; HOT(H_TAG, slot) = h.did_hit() ? TAG_SHADE : TAG_MISS; }
                     else HOT(H_CUR, slot) = cur;
                 }
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 }
                 if (h.did_hit()) {
                     SETH(H_T, slot, h.t);
-                    HOT(H_REF, slot) = h.ref | (h.src << 30);
+                    COLD(C_REF, slot) = h.ref | (h.src << 30);
                     HOT(H_TAG, slot) = TAG_SHADE;
                 } else { // escaped: shader.wgsl:1222-1231
                     float u, v;
@@ -248,9 +253,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 const V3 d = v3(HOTF(H_DX, slot), HOTF(H_DY, slot), HOTF(H_DZ, slot));
                 Hit h;
                 h.t = HOTF(H_T, slot);
-                const uint32_t hr = HOT(H_REF, slot);
+                const uint32_t hr = COLD(C_REF, slot);
                 h.ref = hr & 0x3fffffffu; h.src = hr >> 30;
-                h.u = HOTF(H_U, slot); h.v = HOTF(H_V, slot);
+                h.u = COLDF(C_U, slot); h.v = COLDF(C_V, slot);
                 uint32_t rng = COLD(C_RNG, slot);
                 const V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
                 V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
