@@ -413,7 +413,7 @@ struct rsrt_context {
     std::vector<hipEvent_t> event_pool;
     int blocks_per_cu[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // [lds][kernel variant]
     int kernel_variant = 3; // 0 megakernel, 1..3 wave-pool with 64/128/192 slots per wave
-    uint32_t trace_budget = 24; // traversal steps per TRACE invocation before a ray is re-queued
+    uint32_t trace_budget = 12; // traversal steps per TRACE invocation before a ray is re-queued
     unsigned long long debug_words[32] = {0};
 };
 
