@@ -931,6 +931,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     if (const char *e = getenv("RSRT_SAMPLE_BUFFER_MB")) { long v = atol(e); if (v > 0) budget = (size_t)v << 20; }
     const size_t per_sample = (size_t)P.n_slots * 3 * sizeof(float);
     uint32_t pass_samples = (uint32_t)std::max<size_t>(1, std::min<size_t>(sample_count, budget / per_sample));
+    pass_samples = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(pass_samples, 0xffffffffull / P.n_slots)); // slot ids are 32-bit
     const size_t need = per_sample * pass_samples;
     if (need > ctx->sample_buf_bytes) {
         HIP_TRY(ctx, hipStreamSynchronize(stream));

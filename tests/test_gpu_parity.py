@@ -280,6 +280,20 @@ def test_stats_window_survives_many_small_calls(big_env):
     assert np.array_equal(util.bits(img_one), util.bits(img_many))
 
 
+def test_config5_geometry_partitioned(big_env):
+    """BASELINE config 5 geometry: 3840x2160, framebuffer tiled over 8 ranks.  Two of the eight ranks at
+    1 spp: every owned pixel equals the oracle's, every other pixel is untouched."""
+    sc = R.Scene.load_toml(util.scene_path("house"))
+    w, h = 3840, 2160
+    ref, _ = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), w, h, 0, 1, 8, fast=True)
+    for rank in (0, 5):
+        part, st = gpu_render(sc, big_env, w, h, 0, 1, 8, partition_args=(rank, 8, 16, 16))
+        m = partition.owned_mask(w, h, rank, 8)
+        assert np.array_equal(util.bits(part[m]), util.bits(ref[m]))
+        assert np.all(part[~m] == 0)
+        assert st["paths"] == int(m.sum())
+
+
 def test_mean_f16_and_alpha(big_env):
     sc = R.Scene.load_toml(util.scene_path("default"))
     st = R.State.new(sc, big_env, 64, 40)
