@@ -66,6 +66,9 @@ def build_hip(force=False, extra_flags=(), instrument=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     target = HIP_LIB.replace(".so", "_instr.so") if instrument else HIP_LIB
     flags = list(extra_flags) + (["-DRT_INSTRUMENT"] if instrument else [])
+    if os.environ.get("RSRT_HIPCC_FLAGS"):  # experiment knob: extra compiler flags
+        flags += os.environ["RSRT_HIPCC_FLAGS"].split()
+        force = True
     if os.environ.get("RSRT_WPS"):  # experiment knob: waves per SIMD the pool kernel is compiled for
         flags.append("-DRT_POOL_WAVES_PER_SIMD=" + os.environ["RSRT_WPS"])
         force = True
@@ -76,7 +79,7 @@ def build_hip(force=False, extra_flags=(), instrument=False):
         if force or _newer(target, _deps("hip")):
             tmp = target + ".tmp%d" % os.getpid()
             _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                  "-fno-fast-math", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", INCLUDE, "-o", tmp] + flags + srcs)
+                  "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", INCLUDE, "-o", tmp] + flags + srcs)
             os.replace(tmp, target)
     return target
 

@@ -46,6 +46,7 @@ struct RenderParams {
     uint32_t chunk_px, n_subtiles; // a chunk covers chunk_px consecutive pixels of a tile (tile_px / n_subtiles)
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
     uint32_t trace_budget;
+    uint32_t trace_rounds;
     uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
     float *sample_buf;
     unsigned int *work_counter;
@@ -61,11 +62,11 @@ __device__ __forceinline__ SceneView<true> make_view<true>(const DevScene &sc)
     SceneView<true> v;
     v.o_nodes = 0;
     v.o_prims = v.o_nodes + 2u * sc.n_nodes;
-    v.o_trin = v.o_prims + 4u * sc.n_prims;
+    v.o_esc = v.o_prims + 4u * sc.n_prims;
+    v.o_trin = v.o_esc + (8u * sc.n_nodes + 3u) / 4u;
     v.o_mats = v.o_trin + 3u * sc.n_tris;
     v.o_fbs = v.o_mats + 4u * sc.n_materials;
     v.o_fbp = v.o_fbs + 4u * sc.n_spheres;
-    v.o_esc = v.o_fbp + 4u * sc.n_planes;
     return v;
 }
 template <>
@@ -74,8 +75,8 @@ __device__ __forceinline__ SceneView<false> make_view<false>(const DevScene &sc)
     return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.escape};
 }
 
-// Copies the scene image into LDS (the six arrays are contiguous in one device allocation, in
-// the order make_view<true> assumes).
+// Copies the scene image into LDS (the arrays are contiguous in one device allocation, in the order
+// make_view<true> assumes).
 __device__ __forceinline__ void stage_scene_lds(const DevScene &sc)
 {
     for (uint32_t i = threadIdx.x; i < sc.lds_float4s; i += blockDim.x) rt_smem[i] = sc.nodes[i];
@@ -377,6 +378,28 @@ struct Env {
 
 } // namespace
 
+// Kernel variants (RSRT_KERNEL): 0 = lockstep megakernel (first kernel); 1 = wave pool with in-lane primitive
+// loops (previous production kernel, and the fallback when a scene does not fit the pair encoding);
+// 2, 3 = wave pool with wave-cooperative primitive tests, 160 / 192 slots per wave.
+struct KernelVariant { uint32_t pool; bool pairs; };
+#define RT_N_VARIANTS 5
+static const KernelVariant kVariants[RT_N_VARIANTS] = {{0, false}, {192, false}, {160, true}, {192, true}, {160, false}};
+static const void *variant_function(int kv, bool lds)
+{
+    switch (kv * 2 + (lds ? 1 : 0)) {
+    case 0: return reinterpret_cast<const void *>(&rt_render_kernel<false>);
+    case 1: return reinterpret_cast<const void *>(&rt_render_kernel<true>);
+    case 2: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192, false>);
+    case 3: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192, false>);
+    case 4: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 160, true>);
+    case 5: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 160, true>);
+    case 6: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192, true>);
+    case 7: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192, true>);
+    case 8: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 160, false>);
+    default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 160, false>);
+    }
+}
+
 struct rsrt_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -411,8 +434,9 @@ struct rsrt_context {
     unsigned long long base_counts[3] = {0, 0, 0};
     uint32_t cum_launches = 0, base_launches = 0;
     std::vector<hipEvent_t> event_pool;
-    int blocks_per_cu[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // [lds][kernel variant]
-    int kernel_variant = 3; // 0 megakernel, 1..3 wave-pool with 64/128/192 slots per wave
+    int blocks_per_cu[2][RT_N_VARIANTS] = {}; // [lds][kernel variant]
+    int kernel_variant = 3; // index into kVariants
+    uint32_t trace_rounds = 1;  // collect/test rounds per TRACE invocation of the wave-cooperative kernel
     uint32_t trace_budget = 12; // traversal steps per TRACE invocation before a ray is re-queued
     unsigned long long debug_words[32] = {0};
 };
@@ -591,15 +615,13 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
         delete ctx;
         return RSRT_ERR_HIP;
     }
-    const void *big_lds[] = {reinterpret_cast<const void *>(&rt_render_kernel<true>), reinterpret_cast<const void *>(&rt_render_kernel<false>),
-                             reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 64>), reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 64>),
-                             reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 128>), reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 128>),
-                             reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192>), reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192>)};
-    for (const void *f : big_lds) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (const char *kv = getenv("RSRT_KERNEL")) { // 0 = lockstep megakernel, 1/2/3 = wave-pool kernel with 64/128/192 slots per wave
+    for (int kv = 0; kv < RT_N_VARIANTS; kv++)
+        for (int lds = 0; lds < 2; lds++) (void)hipFuncSetAttribute(variant_function(kv, lds != 0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (const char *kv = getenv("RSRT_KERNEL")) { // see kVariants
         int v = atoi(kv);
-        if (v >= 0 && v <= 3) ctx->kernel_variant = v;
+        if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
     }
+    if (const char *tr = getenv("RSRT_TRACE_ROUNDS")) { int v = atoi(tr); if (v > 0) ctx->trace_rounds = (uint32_t)v; }
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_cast_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
@@ -707,15 +729,23 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         }
     }
     const size_t esc_f4 = (8ull * n_nodes + 3) / 4;
-    // ---- build the device image: nodes | prims | tri normals | materials | fb spheres | fb planes | escape links
+    // ---- build the device image: nodes | prims | escape links | tri normals | materials | fb spheres | fb planes
     const size_t n_f4 = 2ull * n_nodes + 4ull * n_primitives + 3ull * n_triangles + 4ull * n_materials + 4ull * n_spheres + 4ull * n_planes + esc_f4;
     std::vector<float4> img(n_f4);
     float4 *p = img.data();
     float4 *p_nodes = p;
+    uint32_t max_leaf = 0;
     for (uint32_t i = 0; i < n_nodes; i++, p += 2) {
         const rsrt_bvh_node &nd = nodes[i];
         p[0] = f4(nd.bounds_min[0], nd.bounds_min[1], nd.bounds_min[2], u2f(nd.primitives_or_second_child_index));
-        p[1] = f4(nd.bounds_max[0], nd.bounds_max[1], nd.bounds_max[2], u2f(nd.primitives_len | (nd.split_axis << 16)));
+        uint32_t hi = nd.split_axis; // interior: split axis; leaf: 2-bit types of its first 8 primitives
+        if (nd.primitives_len != 0) {
+            hi = 0;
+            for (uint32_t k = 0; k < std::min<uint32_t>(nd.primitives_len, 8u); k++)
+                hi |= (primitives[nd.primitives_or_second_child_index + k].primitive_type & 3u) << (2u * k);
+            max_leaf = std::max(max_leaf, nd.primitives_len);
+        }
+        p[1] = f4(nd.bounds_max[0], nd.bounds_max[1], nd.bounds_max[2], u2f(nd.primitives_len | (hi << 16)));
     }
     float4 *p_prims = p;
     for (uint32_t i = 0; i < n_primitives; i++, p += 4) {
@@ -724,6 +754,9 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         else if (pi.primitive_type == 1) make_plane_record(planes[pi.index], p);
         else make_triangle_record(triangles[pi.index], pi.index, vertices, p);
     }
+    float4 *p_esc = p;
+    memcpy(p_esc, escape.data(), escape.size() * sizeof(uint32_t));
+    p += esc_f4;
     float4 *p_trin = p;
     for (uint32_t i = 0; i < n_triangles; i++, p += 3) {
         const float *a = normals[triangles[i].normal_0].v, *b = normals[triangles[i].normal_1].v, *c = normals[triangles[i].normal_2].v;
@@ -737,8 +770,6 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     for (uint32_t i = 0; i < n_spheres; i++, p += 4) make_sphere_record(spheres[i], p);
     float4 *p_fbp = p;
     for (uint32_t i = 0; i < n_planes; i++, p += 4) make_plane_record(planes[i], p);
-    float4 *p_esc = p;
-    memcpy(p_esc, escape.data(), escape.size() * sizeof(uint32_t));
 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->scene_blob) { (void)hipFree(ctx->scene_blob); ctx->scene_blob = nullptr; }
@@ -756,6 +787,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.n_nodes = n_nodes; sc.n_prims = n_primitives; sc.n_tris = n_triangles; sc.n_materials = n_materials;
     sc.n_spheres = n_spheres; sc.n_planes = n_planes;
     sc.stack_entries = depth + 1;
+    sc.pairs_ok = (max_leaf * RT_LEAFQ <= 63u && n_primitives < (1u << RT_PAIR_REF_BITS)) ? 1u : 0u;
     const size_t stack_bytes = (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t);
     if (stack_bytes > 128 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh depth %u exceeds the supported traversal stack", depth);
     sc.lds_float4s = (n_f4 * sizeof(float4) <= 24 * 1024) ? (uint32_t)n_f4 : 0u; // LDS image only while it leaves room for the path pools
@@ -923,6 +955,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.n_slots = P.n_owned_tiles * tile_px;
     P.work_counter = ctx->work_counter;
     P.trace_budget = ctx->trace_budget;
+    P.trace_rounds = ctx->trace_rounds;
     P.stats = ctx->dev_stats;
     if (P.n_slots == 0) return RSRT_OK;
 
@@ -942,23 +975,14 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.sample_buf = ctx->sample_buf;
 
     const bool lds = P.scene.lds_float4s != 0;
-    const int kv = ctx->kernel_variant;
-    const uint32_t pool = kv == 1 ? 64u : (kv == 2 ? 128u : 192u);
+    int kv = ctx->kernel_variant;
+    if (kVariants[kv].pairs && !P.scene.pairs_ok) kv = 1; // leaves too long / too many records for the pair encoding
+    const uint32_t pool = kVariants[kv].pool;
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
-                                : scene_bytes + (size_t)(RT_BLOCK / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
+                                : scene_bytes + (size_t)(RT_BLOCK / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + (kVariants[kv].pairs ? 128u + 2u * RT_LIST_CAP : 64u));
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
-    const void *kfn = nullptr;
-    switch (kv * 2 + (lds ? 1 : 0)) {
-    case 0: kfn = reinterpret_cast<const void *>(&rt_render_kernel<false>); break;
-    case 1: kfn = reinterpret_cast<const void *>(&rt_render_kernel<true>); break;
-    case 2: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 64>); break;
-    case 3: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 64>); break;
-    case 4: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 128>); break;
-    case 5: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 128>); break;
-    case 6: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192>); break;
-    default: kfn = reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192>); break;
-    }
+    const void *kfn = variant_function(kv, lds);
     int &bpc = ctx->blocks_per_cu[lds ? 1 : 0][kv];
     if (bpc == 0) {
         int nb = 0;

@@ -28,25 +28,28 @@
 #pragma once
 #include "rt_device.h"
 
-enum HotField { H_OX, H_OY, H_OZ, H_DX, H_DY, H_DZ, H_CUR, H_T, H_TAG, H_COUNT };
+enum HotField { H_OX, H_OY, H_OZ, H_DX, H_DY, H_DZ, H_T, H_CT, H_COUNT }; // H_CT: traversal cursor << 3 | stage tag
 enum ColdField {
     C_TX, C_TY, C_TZ, C_LX, C_LY, C_LZ, C_LASTPDF, C_RNG, C_BOUNCE, C_OUT,
     C_WX, C_WY, C_WZ,             // direction the path arrived with at the current hit (wo = -w)
     C_NX, C_NY, C_NZ, C_MAT,      // shading normal and material of the current hit
     C_ERX, C_ERY, C_ERZ, C_EPDF, C_COS, // NEE sample: radiance, pdf, cos (0 = no contribution)
-    C_REF, C_U, C_V,              // best hit of the extension ray: record, barycentrics (rewritten only when a TRACE call improves it)
+    C_REF,                        // best hit of the extension ray: record | source << 30 (rewritten only when a TRACE call improves it)
     C_COUNT
 };
 enum PoolTag { TAG_FREE = 0, TAG_TRACE_EXT = 1, TAG_TRACE_SHADOW = 2, TAG_MISS = 3, TAG_SHADE = 4, TAG_BSDF = 5, TAG_IDLE = 6 };
 enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_BSDF = 4, ST_COUNT = 5 };
 
-template <uint32_t POOL>
+template <uint32_t POOL, bool PAIRS>
 struct PoolLayout {
     static constexpr uint32_t kSlotsPerLane = (POOL + 63u) / 64u;
     static constexpr uint32_t kHotDwords = H_COUNT * POOL;
-    static constexpr uint32_t kListDwords = 64u;
+    // scratch after the hot columns: the compaction list (64), or for PAIRS 64 u64 keys + two pair lists
+    // (the compaction list is dead once every lane has read its slot and shares the first pair list)
+    static constexpr uint32_t kListDwords = PAIRS ? 128u + 2u * RT_LIST_CAP : 64u;
     static constexpr uint32_t kWaveLdsDwords = kHotDwords + kListDwords;
     static constexpr uint32_t kWaveColdDwords = C_COUNT * POOL;
+    static_assert(kHotDwords % 2u == 0u && kWaveLdsDwords % 2u == 0u, "u64 keys need 8-byte alignment");
 };
 
 RT_DEV uint32_t stage_of_tag(uint32_t tag)
@@ -56,12 +59,12 @@ RT_DEV uint32_t stage_of_tag(uint32_t tag)
 }
 
 #ifndef RT_POOL_WAVES_PER_SIMD
-#define RT_POOL_WAVES_PER_SIMD 4
+#define RT_POOL_WAVES_PER_SIMD 5
 #endif
-template <bool LDS, uint32_t POOL>
+template <bool LDS, uint32_t POOL, bool PAIRS>
 __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
 {
-    typedef PoolLayout<POOL> L;
+    typedef PoolLayout<POOL, PAIRS> L;
     const DevScene &sc = P.scene;
     if (LDS) stage_scene_lds(sc);
     const SceneView<LDS> S = make_view<LDS>(sc);
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
     const uint32_t wave = threadIdx.x / RT_WAVE;
     uint32_t *const lds32 = reinterpret_cast<uint32_t *>(rt_smem + sc.lds_float4s);
     uint32_t *const W = lds32 + wave * L::kWaveLdsDwords; // this wave's hot columns
-    uint32_t *const list = W + L::kHotDwords;
+    uint32_t *const list = W + L::kHotDwords + (PAIRS ? 128u : 0u);
     uint32_t *const G = P.cold_state + (size_t)(blockIdx.x * (RT_BLOCK / RT_WAVE) + wave) * L::kWaveColdDwords; // cold columns
     const bool prune = (P.flags & RSRT_FLAG_PRUNE) != 0;
     const bool anyhit_shadow = !(P.flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
@@ -78,12 +81,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
 #define HOT(f, slot) W[(f) * POOL + (slot)]
 #define HOTF(f, slot) as_f(W[(f) * POOL + (slot)])
 #define SETH(f, slot, val) W[(f) * POOL + (slot)] = as_u(val)
+#define TAG_OF(slot) (W[H_CT * POOL + (slot)] & 7u)
+#define SET_TAG(slot, tag) W[H_CT * POOL + (slot)] = (uint32_t)(tag)              /* cursor := root (0) */
+#define SET_CUR_TAG(slot, cur, tag) W[H_CT * POOL + (slot)] = ((cur) << 3) | (uint32_t)(tag)
 #define COLD(f, slot) G[(f) * POOL + (slot)]
 #define COLDF(f, slot) as_f(G[(f) * POOL + (slot)])
 #define SETC(f, slot, val) G[(f) * POOL + (slot)] = as_u(val)
 
     for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
-        if (lane + 64u * k < POOL) HOT(H_TAG, lane + 64u * k) = TAG_FREE;
+        if (lane + 64u * k < POOL) SET_TAG(lane + 64u * k, TAG_FREE);
 
     uint32_t chunk_next = 0, chunk_left = 0, chunk_tile_slot0 = 0, chunk_tx0 = 0, chunk_ty0 = 0, chunk_s0 = 0, chunk_p0 = 0;
     bool exhausted = false;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
         uint32_t tags[L::kSlotsPerLane];
         uint32_t count[ST_COUNT] = {0, 0, 0, 0, 0};
         for (uint32_t k = 0; k < L::kSlotsPerLane; k++) {
-            tags[k] = (lane + 64u * k < POOL) ? HOT(H_TAG, lane + 64u * k) : (uint32_t)TAG_IDLE;
+            tags[k] = (lane + 64u * k < POOL) ? TAG_OF(lane + 64u * k) : (uint32_t)TAG_IDLE;
             const uint32_t st = stage_of_tag(tags[k]);
             for (uint32_t s = 0; s < ST_COUNT; s++) count[s] += (uint32_t)__popcll(__ballot(st == s));
         }
@@ -161,7 +167,6 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                         start_path(P, px, py, P.sample_begin + srel, ps);
                         SETH(H_OX, slot, ps.o.x); SETH(H_OY, slot, ps.o.y); SETH(H_OZ, slot, ps.o.z);
                         SETH(H_DX, slot, ps.d.x); SETH(H_DY, slot, ps.d.y); SETH(H_DZ, slot, ps.d.z);
-                        HOT(H_CUR, slot) = 0u;
                         SETH(H_T, slot, RT_INFINITY);
                         SETC(C_TX, slot, 1.0f); SETC(C_TY, slot, 1.0f); SETC(C_TZ, slot, 1.0f);
                         SETC(C_LX, slot, 0.0f); SETC(C_LY, slot, 0.0f); SETC(C_LZ, slot, 0.0f);
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                         COLD(C_RNG, slot) = ps.rng;
                         COLD(C_BOUNCE, slot) = 0u;
                         COLD(C_OUT, slot) = srel * P.n_slots + chunk_tile_slot0 + p;
-                        HOT(H_TAG, slot) = TAG_TRACE_EXT;
+                        SET_TAG(slot, TAG_TRACE_EXT);
                         n_paths++;
                     }
                     // an out-of-frame pixel of an edge tile: the slot stays FREE and is offered again
@@ -180,35 +185,69 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
             }
             if (exhausted) { // nothing more to hand out: park every FREE slot
                 for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
-                    if (lane + 64u * k < POOL && HOT(H_TAG, lane + 64u * k) == TAG_FREE) HOT(H_TAG, lane + 64u * k) = TAG_IDLE;
+                    if (lane + 64u * k < POOL && TAG_OF(lane + 64u * k) == TAG_FREE) SET_TAG(lane + 64u * k, TAG_IDLE);
+            }
+        } else if (best == ST_TRACE && PAIRS) {
+            // ---------------- TRACE, wave-cooperative: each lane walks the boxes of its own ray and collects
+            // leaves; the primitives of all held leaves are tested by the whole wave (rt_device.h,
+            // test_leaves_as_a_wave).  ALL 64 lanes run this block: lanes without a ray still test pairs.
+            const uint32_t ct = on ? HOT(H_CT, slot) : (RT_END << 3);
+            const bool shadow = (ct & 7u) == TAG_TRACE_SHADOW;
+            const bool anyhit = shadow && anyhit_shadow;
+            const V3 o = on ? v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot)) : v3(0.0f, 0.0f, 0.0f);
+            const V3 d = on ? v3(HOTF(H_DX, slot), HOTF(H_DY, slot), HOTF(H_DZ, slot)) : v3(1.0f, 1.0f, 1.0f);
+            uint32_t cur = ct >> 3;
+            float best_t = on ? HOTF(H_T, slot) : 0.0f;
+            uint32_t best_ref = 0xffffffffu; // "not improved by this call": C_REF of an earlier call stays
+            const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+            const uint32_t ebase = octant * sc.n_nodes;
+            unsigned long long *const keys = reinterpret_cast<unsigned long long *>(W + L::kHotDwords);
+            uint32_t *const tri_list = W + L::kHotDwords + 128u, *const oth_list = tri_list + RT_LIST_CAP;
+            __builtin_amdgcn_wave_barrier(); // every lane has read its slot from `list` (= tri_list) by now
+            for (uint32_t round = 0; round < P.trace_rounds; round++) {
+                LeafQueue q;
+                DBG_STAMP(27); // TRACE prologue (and, after the first round, the round's tail)
+                trace_collect(DBG_ARG S, ebase, octant, o, inv, prune, best_t, P.trace_budget, cur, q);
+                DBG_STAMP(23);
+                test_leaves_as_a_wave(DBG_ARG S, lane, o, d, q, keys, tri_list, oth_list, best_t, best_ref);
+                DBG_STAMP(24);
+                if (anyhit & (best_t < RT_INFINITY)) cur = RT_END; // the shadow query only wants to know whether anything is hit
+                if (__ballot(cur != RT_END) == 0ull) break;
+            }
+            if (on) {
+                SETH(H_T, slot, best_t);
+                if (!shadow && best_ref != 0xffffffffu) COLD(C_REF, slot) = best_ref;
+                if (cur == RT_END) {
+                    if (shadow) { n_shadow++; SET_TAG(slot, TAG_BSDF); } // H_T < INFINITY <=> occluded
+                    else { n_ext++; SET_TAG(slot, best_t < RT_INFINITY ? TAG_SHADE : TAG_MISS); }
+                } else {
+                    SET_CUR_TAG(slot, cur, ct & 7u);
+                }
             }
         } else if (best == ST_TRACE) {
-            // ---------------- TRACE: cast_ray_bvh for extension and shadow rays together.  The slot's
-            // o / d ARE the ray to trace (SHADE already moved a shadow ray's origin to the hit point).
+            // ---------------- TRACE, in-lane (the A/B baseline, and the fallback for scenes whose leaves or
+            // record count do not fit the pair encoding): the slot's o / d ARE the ray to trace.
             if (on) {
-                const bool shadow = HOT(H_TAG, slot) == TAG_TRACE_SHADOW;
+                const uint32_t ct = HOT(H_CT, slot);
+                const bool shadow = (ct & 7u) == TAG_TRACE_SHADOW;
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
                 const V3 d = v3(HOTF(H_DX, slot), HOTF(H_DY, slot), HOTF(H_DZ, slot));
                 // resume (or start: cur = root, best = INFINITY) the threaded traversal for a bounded number of steps
                 Hit h;
-                uint32_t cur = HOT(H_CUR, slot);
+                uint32_t cur = ct >> 3;
                 h.src = SRC_BVH;
-                h.t = HOTF(H_T, slot); h.ref = 0; h.u = h.v = 0.0f; // ref/u/v of an earlier call stay in the cold columns unless beaten
+                h.t = HOTF(H_T, slot); h.ref = 0; h.u = h.v = 0.0f; // ref of an earlier call stays in the cold column unless beaten
                 const float t_in = h.t;
                 trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
                 const bool done = cur == RT_END;
                 SETH(H_T, slot, h.t);
-                if (shadow) {
-                    if (done) { n_shadow++; HOT(H_TAG, slot) = TAG_BSDF; } // H_T < INFINITY <=> occluded
-                    else HOT(H_CUR, slot) = cur;
+                if (!shadow && h.t < t_in) COLD(C_REF, slot) = h.ref; // this call found a closer hit
+                if (done) {
+                    if (shadow) { n_shadow++; SET_TAG(slot, TAG_BSDF); } // H_T < INFINITY <=> occluded
+                    else { n_ext++; SET_TAG(slot, h.did_hit() ? TAG_SHADE : TAG_MISS); }
                 } else {
-                    if (h.t < t_in) { // this call found a closer hit
-                        COLD(C_REF, slot) = h.ref;
-                        SETC(C_U, slot, h.u);
-                        SETC(C_V, slot, h.v);
-                    }
-                    if (done) { n_ext++; HOT(H_TAG, slot) = h.did_hit() ? TAG_SHADE : TAG_MISS; }
-                    else HOT(H_CUR, slot) = cur;
+                    SET_CUR_TAG(slot, cur, ct & 7u);
                 }
             }
         } else if (best == ST_MISS) {
@@ -231,7 +270,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 if (h.did_hit()) {
                     SETH(H_T, slot, h.t);
                     COLD(C_REF, slot) = h.ref | (h.src << 30);
-                    HOT(H_TAG, slot) = TAG_SHADE;
+                    SET_TAG(slot, TAG_SHADE);
                 } else { // escaped: shader.wgsl:1222-1231
                     float u, v;
                     direction_to_equirectangular_uv(d, u, v);
@@ -243,7 +282,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                     Lr = Lr + T * sky * w;
                     float *dst = P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u;
                     dst[0] = Lr.x; dst[1] = Lr.y; dst[2] = Lr.z;
-                    HOT(H_TAG, slot) = TAG_FREE;
+                    SET_TAG(slot, TAG_FREE);
                 }
             }
         } else if (best == ST_SHADE) {
@@ -255,7 +294,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 h.t = HOTF(H_T, slot);
                 const uint32_t hr = COLD(C_REF, slot);
                 h.ref = hr & 0x3fffffffu; h.src = hr >> 30;
-                h.u = COLDF(C_U, slot); h.v = COLDF(C_V, slot);
+                hit_barycentrics(S, h, o, d); // not carried through the traversal: the same test gives the same bits
                 uint32_t rng = COLD(C_RNG, slot);
                 const V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
                 V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
@@ -276,9 +315,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 // the next ray — the shadow ray now, the bounce later — starts at the hit point
                 SETH(H_OX, slot, surf.point.x); SETH(H_OY, slot, surf.point.y); SETH(H_OZ, slot, surf.point.z);
                 SETH(H_DX, slot, es.direction.x); SETH(H_DY, slot, es.direction.y); SETH(H_DZ, slot, es.direction.z);
-                HOT(H_CUR, slot) = 0u;
                 SETH(H_T, slot, RT_INFINITY); // BSDF reads "H_T < INFINITY" as "occluded"
-                HOT(H_TAG, slot) = want_shadow ? TAG_TRACE_SHADOW : TAG_BSDF;
+                SET_TAG(slot, want_shadow ? TAG_TRACE_SHADOW : TAG_BSDF);
             }
         } else {
             // ---------------- BSDF: NEE contribution, BSDF sample, throughput (shader.wgsl:1251-1299)
@@ -324,7 +362,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 if (finished) {
                     float *dst = P.sample_buf + (size_t)out * 3u;
                     dst[0] = Lr.x; dst[1] = Lr.y; dst[2] = Lr.z;
-                    HOT(H_TAG, slot) = TAG_FREE;
+                    SET_TAG(slot, TAG_FREE);
                 } else {
                     SETC(C_LASTPDF, slot, bs.pdf);
                     SETC(C_TX, slot, T.x); SETC(C_TY, slot, T.y); SETC(C_TZ, slot, T.z);
@@ -332,9 +370,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                     COLD(C_RNG, slot) = rng;
                     COLD(C_BOUNCE, slot) = bounce;
                     SETH(H_DX, slot, bs.dir.x); SETH(H_DY, slot, bs.dir.y); SETH(H_DZ, slot, bs.dir.z); // origin stays the hit point
-                    HOT(H_CUR, slot) = 0u;
                     SETH(H_T, slot, RT_INFINITY);
-                    HOT(H_TAG, slot) = TAG_TRACE_EXT;
+                    SET_TAG(slot, TAG_TRACE_EXT);
                 }
                 (void)point;
             }
@@ -344,6 +381,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
 #undef HOT
 #undef HOTF
 #undef SETH
+#undef TAG_OF
+#undef SET_TAG
+#undef SET_CUR_TAG
 #undef COLD
 #undef COLDF
 #undef SETC

@@ -48,7 +48,7 @@ def lib():
     if _lib is None:
         try:
             import os
-            path = _build.build_hip(instrument=os.environ.get("RSRT_INSTRUMENT") == "1")
+            path = os.environ.get("RSRT_LIB") or _build.build_hip(instrument=os.environ.get("RSRT_INSTRUMENT") == "1")  # RSRT_LIB: experiment builds (tools/flag_sweep.sh)
             L = C.CDLL(path)
         except Exception as e:  # noqa: BLE001
             raise RsrtError("librsrt.so (the HIP integrator) is not available: %s" % e) from e
