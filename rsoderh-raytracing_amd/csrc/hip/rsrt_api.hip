@@ -46,7 +46,6 @@ struct RenderParams {
     uint32_t chunk_px, n_subtiles; // a chunk covers chunk_px consecutive pixels of a tile (tile_px / n_subtiles)
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
     uint32_t trace_budget;
-    uint32_t trace_rounds;
     uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
     float *sample_buf;
     unsigned int *work_counter;
@@ -378,25 +377,19 @@ struct Env {
 
 } // namespace
 
-// Kernel variants (RSRT_KERNEL): 0 = lockstep megakernel (first kernel); 1 = wave pool with in-lane primitive
-// loops (previous production kernel, and the fallback when a scene does not fit the pair encoding);
-// 2, 3 = wave pool with wave-cooperative primitive tests, 160 / 192 slots per wave.
-struct KernelVariant { uint32_t pool; bool pairs; };
-#define RT_N_VARIANTS 5
-static const KernelVariant kVariants[RT_N_VARIANTS] = {{0, false}, {192, false}, {160, true}, {192, true}, {160, false}};
+// Kernel variants (RSRT_KERNEL): 0 = lockstep megakernel (first kernel); 1, 2 = stage-scheduled wave-pool kernel
+// with 192 / 160 path slots per wave (160: five workgroups per CU fit in LDS).
+#define RT_N_VARIANTS 3
+static const uint32_t kVariantPool[RT_N_VARIANTS] = {0, 192, 160};
 static const void *variant_function(int kv, bool lds)
 {
     switch (kv * 2 + (lds ? 1 : 0)) {
     case 0: return reinterpret_cast<const void *>(&rt_render_kernel<false>);
     case 1: return reinterpret_cast<const void *>(&rt_render_kernel<true>);
-    case 2: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192, false>);
-    case 3: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192, false>);
-    case 4: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 160, true>);
-    case 5: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 160, true>);
-    case 6: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192, true>);
-    case 7: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192, true>);
-    case 8: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 160, false>);
-    default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 160, false>);
+    case 2: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192>);
+    case 3: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192>);
+    case 4: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 160>);
+    default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 160>);
     }
 }
 
@@ -435,8 +428,7 @@ struct rsrt_context {
     uint32_t cum_launches = 0, base_launches = 0;
     std::vector<hipEvent_t> event_pool;
     int blocks_per_cu[2][RT_N_VARIANTS] = {}; // [lds][kernel variant]
-    int kernel_variant = 3; // index into kVariants
-    uint32_t trace_rounds = 1;  // collect/test rounds per TRACE invocation of the wave-cooperative kernel
+    int kernel_variant = 2; // index into kVariantPool
     uint32_t trace_budget = 12; // traversal steps per TRACE invocation before a ray is re-queued
     unsigned long long debug_words[32] = {0};
 };
@@ -617,11 +609,10 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     }
     for (int kv = 0; kv < RT_N_VARIANTS; kv++)
         for (int lds = 0; lds < 2; lds++) (void)hipFuncSetAttribute(variant_function(kv, lds != 0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (const char *kv = getenv("RSRT_KERNEL")) { // see kVariants
+    if (const char *kv = getenv("RSRT_KERNEL")) { // see kVariantPool
         int v = atoi(kv);
         if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
     }
-    if (const char *tr = getenv("RSRT_TRACE_ROUNDS")) { int v = atoi(tr); if (v > 0) ctx->trace_rounds = (uint32_t)v; }
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_cast_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
@@ -662,6 +653,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
     DeviceGuard g(ctx->device);
     if (n_nodes == 0 || !nodes) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh_nodes is empty");
+    if (n_nodes >= RT_END) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh_nodes: %u nodes exceed the 29-bit traversal cursor", n_nodes);
     if ((n_materials && !materials) || (n_spheres && !spheres) || (n_planes && !planes) || (n_vertices && !vertices) ||
         (n_normals && !normals) || (n_triangles && !triangles) || (n_primitives && !primitives))
         return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "a non-empty array has a NULL pointer");
@@ -734,18 +726,10 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     std::vector<float4> img(n_f4);
     float4 *p = img.data();
     float4 *p_nodes = p;
-    uint32_t max_leaf = 0;
     for (uint32_t i = 0; i < n_nodes; i++, p += 2) {
         const rsrt_bvh_node &nd = nodes[i];
         p[0] = f4(nd.bounds_min[0], nd.bounds_min[1], nd.bounds_min[2], u2f(nd.primitives_or_second_child_index));
-        uint32_t hi = nd.split_axis; // interior: split axis; leaf: 2-bit types of its first 8 primitives
-        if (nd.primitives_len != 0) {
-            hi = 0;
-            for (uint32_t k = 0; k < std::min<uint32_t>(nd.primitives_len, 8u); k++)
-                hi |= (primitives[nd.primitives_or_second_child_index + k].primitive_type & 3u) << (2u * k);
-            max_leaf = std::max(max_leaf, nd.primitives_len);
-        }
-        p[1] = f4(nd.bounds_max[0], nd.bounds_max[1], nd.bounds_max[2], u2f(nd.primitives_len | (hi << 16)));
+        p[1] = f4(nd.bounds_max[0], nd.bounds_max[1], nd.bounds_max[2], u2f(nd.primitives_len | (nd.split_axis << 16)));
     }
     float4 *p_prims = p;
     for (uint32_t i = 0; i < n_primitives; i++, p += 4) {
@@ -787,7 +771,6 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.n_nodes = n_nodes; sc.n_prims = n_primitives; sc.n_tris = n_triangles; sc.n_materials = n_materials;
     sc.n_spheres = n_spheres; sc.n_planes = n_planes;
     sc.stack_entries = depth + 1;
-    sc.pairs_ok = (max_leaf * RT_LEAFQ <= 63u && n_primitives < (1u << RT_PAIR_REF_BITS)) ? 1u : 0u;
     const size_t stack_bytes = (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t);
     if (stack_bytes > 128 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh depth %u exceeds the supported traversal stack", depth);
     sc.lds_float4s = (n_f4 * sizeof(float4) <= 24 * 1024) ? (uint32_t)n_f4 : 0u; // LDS image only while it leaves room for the path pools
@@ -955,7 +938,6 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.n_slots = P.n_owned_tiles * tile_px;
     P.work_counter = ctx->work_counter;
     P.trace_budget = ctx->trace_budget;
-    P.trace_rounds = ctx->trace_rounds;
     P.stats = ctx->dev_stats;
     if (P.n_slots == 0) return RSRT_OK;
 
@@ -975,12 +957,11 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.sample_buf = ctx->sample_buf;
 
     const bool lds = P.scene.lds_float4s != 0;
-    int kv = ctx->kernel_variant;
-    if (kVariants[kv].pairs && !P.scene.pairs_ok) kv = 1; // leaves too long / too many records for the pair encoding
-    const uint32_t pool = kVariants[kv].pool;
+    const int kv = ctx->kernel_variant;
+    const uint32_t pool = kVariantPool[kv];
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
-                                : scene_bytes + (size_t)(RT_BLOCK / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + (kVariants[kv].pairs ? 128u + 2u * RT_LIST_CAP : 64u));
+                                : scene_bytes + (size_t)(RT_BLOCK / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
     const void *kfn = variant_function(kv, lds);
     int &bpc = ctx->blocks_per_cu[lds ? 1 : 0][kv];

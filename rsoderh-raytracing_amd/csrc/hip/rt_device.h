@@ -29,15 +29,11 @@ struct DbgCounters { unsigned long long c[RT_DBG_N]; };
 #define DBG_ARG dbg,
 #define DBG_ADD(i, v) dbg.c[i] += (v)
 #define DBG_WAVE_TICK(i) do { if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) dbg.c[i] += 1; } while (0)
-#define DBG_T0 const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime()
-#define DBG_T1(i) do { if ((threadIdx.x & 63u) == 0u) dbg.c[i] += __builtin_amdgcn_s_memtime() - dbg_t0; } while (0)
 #else
 #define DBG_DECL
 #define DBG_ARG
 #define DBG_ADD(i, v) do { } while (0)
 #define DBG_WAVE_TICK(i) do { } while (0)
-#define DBG_T0 do { } while (0)
-#define DBG_T1(i) do { } while (0)
 #endif
 
 #define RT_INFINITY 1.70141183460469231732e+38f // shader.wgsl:235
@@ -59,7 +55,6 @@ struct DevScene {
     uint32_t n_nodes, n_prims, n_tris, n_materials, n_spheres, n_planes;
     uint32_t stack_entries;    // per-lane traversal stack entries (tree depth + 1)
     uint32_t lds_float4s;      // float4 count of the LDS image (0 = scene stays in global memory)
-    uint32_t pairs_ok;         // leaves and record count fit the (lane, seq, record) pair encoding of the wave-cooperative tests
 };
 
 struct DevEnv {
@@ -809,171 +804,5 @@ RT_DEV void trace_threaded(DBG_DECL const View &S, uint32_t n_nodes, V3 o, V3 d,
                 j = nq;
             }
         }
-    }
-}
-
-// ------------------------------------------------------------------ wave-cooperative primitive tests
-// The in-lane leaf loop above runs at ~40 % of the lanes, and with mixed primitive types in flight every
-// trip executes all three intersection routines.  Without pruning the traversal is just "enumerate the
-// (ray, primitive) pairs whose leaf boxes are hit, then take the minimum", so the wave can do the
-// enumeration per lane (trace_collect: box steps only, up to RT_LEAFQ leaves) and the tests as a team:
-// every lane appends its pairs to two wave-level lists in LDS (triangles / spheres+planes), the lists
-// are drained 64 pairs at a time — lane i tests pair i, whatever ray it belongs to — and results meet
-// in one 64-bit key per ray, merged with ds_min_u64:
-//     key = f32 bits of t (positive floats order like integers) << 32 | seq
-// seq = position of the primitive in this ray's depth-first order within the round, 1-based; the
-// incumbent best enters with seq 0.  min(key) is therefore "smallest t, and of equal t the one the
-// reference's strict `<` would have kept": bit-identical to the sequential loop.
-// pair = owner lane << 26 | seq << 20 | primitive record; needs seq <= 63 and records < 2^20
-// (rsrt_upload_scene falls back to the in-lane loop for scenes outside that).
-#define RT_PAIR_REF_BITS 20
-#define RT_PAIR_SEQ_BITS 6
-#define RT_LIST_CAP 128u // a list never holds more than 63 + 64 pairs: full batches are drained as they form
-
-struct LeafQueue {
-    uint32_t idx[RT_LEAFQ], len[RT_LEAFQ], types[RT_LEAFQ]; // first record, count, 2-bit types of the first 8
-    uint32_t n;
-};
-
-// Box steps of the threaded traversal until the lane holds RT_LEAFQ leaves or its traversal ends.
-template <class View>
-RT_DEV void trace_collect(DBG_DECL const View &S, uint32_t ebase, uint32_t octant, V3 o, V3 inv, bool prune, float best_t, uint32_t max_steps,
-                          uint32_t &cur, LeafQueue &q)
-{
-    q.n = 0;
-    uint32_t steps = 0;
-#pragma unroll
-    for (int j = 0; j < RT_LEAFQ; j++) q.idx[j] = q.len[j] = q.types[j] = 0u;
-    while (cur != RT_END && q.n < RT_LEAFQ && steps < max_steps) {
-        DBG_WAVE_TICK(10);
-        DBG_ADD(11, 1);
-        steps++;
-        const float4 n0 = S.node(2u * cur), n1 = S.node(2u * cur + 1u);
-        const uint32_t esc = S.esc(ebase + cur);
-        float t_0;
-        bool inside = slab_test(n0, n1, o, inv, t_0);
-        inside = inside & !(prune & (t_0 > best_t));
-        const uint32_t idx = as_u(n0.w), la = as_u(n1.w);
-        const uint32_t len = la & 0xffffu, hi = la >> 16; // hi: split axis (interior) / primitive types (leaf)
-        const bool descend = inside & (len == 0u);
-        const uint32_t near_child = ((octant >> hi) & 1u) ? idx : cur + 1u;
-        if (inside & (len != 0u)) {
-#pragma unroll
-            for (int j = 0; j < RT_LEAFQ; j++) {
-                q.idx[j] = (q.n == (uint32_t)j) ? idx : q.idx[j];
-                q.len[j] = (q.n == (uint32_t)j) ? len : q.len[j];
-                q.types[j] = (q.n == (uint32_t)j) ? hi : q.types[j];
-            }
-            q.n++;
-        }
-        cur = descend ? near_child : esc;
-    }
-}
-
-RT_DEV float lane_read(uint32_t src_lane, float v) { return as_f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)as_u(v))); }
-
-RT_DEV void key_min(unsigned long long *keys, uint32_t owner, float t, uint32_t seq)
-{
-    __hip_atomic_fetch_min(&keys[owner], ((unsigned long long)as_u(t) << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-
-// One batch of <= 64 triangle pairs: lane i tests pairs[i] with the owner lane's ray.
-template <class View>
-RT_DEV void test_triangle_batch(DBG_DECL const View &S, const uint32_t *pairs, uint32_t n, uint32_t lane, V3 o, V3 d, unsigned long long *keys)
-{
-    DBG_T0;
-    DBG_WAVE_TICK(12);
-    const bool act = lane < n;
-    const uint32_t pair = act ? pairs[lane] : 0u;
-    const uint32_t owner = pair >> 26, seq = (pair >> RT_PAIR_REF_BITS) & 63u, rec = pair & ((1u << RT_PAIR_REF_BITS) - 1u);
-    const V3 ro = v3(lane_read(owner, o.x), lane_read(owner, o.y), lane_read(owner, o.z));
-    const V3 rd = v3(lane_read(owner, d.x), lane_read(owner, d.y), lane_read(owner, d.z));
-    const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u);
-    float u, v;
-    const float t = triangle_t(ro, rd, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), u, v);
-    if (act) DBG_ADD(13, 1);
-    if (act & (t >= 0.0f)) key_min(keys, owner, t, seq);
-    DBG_T1(25);
-}
-// ... and of sphere / plane pairs (a minority: one mixed list keeps the number of part-filled batches down)
-template <class View>
-RT_DEV void test_other_batch(DBG_DECL const View &S, const uint32_t *pairs, uint32_t n, uint32_t lane, V3 o, V3 d, unsigned long long *keys)
-{
-    DBG_T0;
-    DBG_WAVE_TICK(15);
-    const bool act = lane < n;
-    const uint32_t pair = act ? pairs[lane] : 0u;
-    const uint32_t owner = pair >> 26, seq = (pair >> RT_PAIR_REF_BITS) & 63u, rec = pair & ((1u << RT_PAIR_REF_BITS) - 1u);
-    const V3 ro = v3(lane_read(owner, o.x), lane_read(owner, o.y), lane_read(owner, o.z));
-    const V3 rd = v3(lane_read(owner, d.x), lane_read(owner, d.y), lane_read(owner, d.z));
-    float u, v;
-    const float t = test_record(S, rec, SRC_BVH, ro, rd, u, v);
-    if (act) DBG_ADD(13, 1);
-    if (act & (t >= 0.0f)) key_min(keys, owner, t, seq);
-    DBG_T1(26);
-}
-
-// The primitive-test half of a round: expand every lane's held leaves into the two lists, drain them,
-// and fold the keys back into the lanes' best hits.  `keys`, `tri_list`, `oth_list`: this wave's LDS
-// scratch (64 u64, 2 x RT_LIST_CAP u32).  Returns through best_t / best_ref (unchanged when nothing
-// closer was found).
-template <class View>
-RT_DEV void test_leaves_as_a_wave(DBG_DECL const View &S, uint32_t lane, V3 o, V3 d, const LeafQueue &q, unsigned long long *keys,
-                                  uint32_t *tri_list, uint32_t *oth_list, float &best_t, uint32_t &best_ref)
-{
-    keys[lane] = (unsigned long long)as_u(best_t) << 32; // the incumbent: seq 0 wins every tie
-    __builtin_amdgcn_wave_barrier();
-    uint32_t n_tri = 0, n_oth = 0;                        // wave-uniform fill levels
-    uint32_t j = 0, i = 0, seq = 1;
-    uint32_t leaf_i = q.idx[0], leaf_l = q.len[0], leaf_t = q.types[0];
-    bool pending = q.n > 0;
-    while (__ballot(pending) != 0ull) {
-        DBG_WAVE_TICK(14);
-        const uint32_t rec = leaf_i + i;
-        uint32_t type = (leaf_t >> (2u * i)) & 3u;
-        if (i >= 8u) type = as_u(S.prim(4u * rec).w) & 3u; // the node word holds the first 8 types
-        const uint32_t pair = (lane << 26) | (seq << RT_PAIR_REF_BITS) | rec;
-        const bool is_tri = pending & (type == PRIM_TRIANGLE), is_oth = pending & (type != PRIM_TRIANGLE);
-        const unsigned long long m_tri = __ballot(is_tri), m_oth = __ballot(is_oth);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (is_tri) tri_list[n_tri + (uint32_t)__popcll(m_tri & below)] = pair;
-        if (is_oth) oth_list[n_oth + (uint32_t)__popcll(m_oth & below)] = pair;
-        n_tri += (uint32_t)__popcll(m_tri);
-        n_oth += (uint32_t)__popcll(m_oth);
-        // next primitive of this lane
-        i++;
-        seq++;
-        const bool next_leaf = pending & (i == leaf_l);
-        i = next_leaf ? 0u : i;
-        j += next_leaf ? 1u : 0u;
-#pragma unroll
-        for (int k = 1; k < RT_LEAFQ; k++) {
-            const bool take = next_leaf & (j == (uint32_t)k);
-            leaf_i = take ? q.idx[k] : leaf_i;
-            leaf_l = take ? q.len[k] : leaf_l;
-            leaf_t = take ? q.types[k] : leaf_t;
-        }
-        pending = pending & (j < q.n);
-        // drain full batches from the top of each list (the remainder stays at the bottom)
-        if (n_tri >= 64u) { n_tri -= 64u; test_triangle_batch(DBG_ARG S, tri_list + n_tri, 64u, lane, o, d, keys); }
-        if (n_oth >= 64u) { n_oth -= 64u; test_other_batch(DBG_ARG S, oth_list + n_oth, 64u, lane, o, d, keys); }
-    }
-    if (n_tri) test_triangle_batch(DBG_ARG S, tri_list, n_tri, lane, o, d, keys);
-    if (n_oth) test_other_batch(DBG_ARG S, oth_list, n_oth, lane, o, d, keys);
-    __builtin_amdgcn_wave_barrier();
-    const unsigned long long key = keys[lane];
-    const uint32_t won = (uint32_t)key & 63u;
-    if (won != 0u) { // seq -> record: walk the held leaves
-        best_t = as_f((uint32_t)(key >> 32));
-        uint32_t r = won - 1u, ref = 0u;
-        bool resolved = false;
-#pragma unroll
-        for (int k = 0; k < RT_LEAFQ; k++) {
-            const bool here = !resolved & (r < q.len[k]);
-            ref = here ? q.idx[k] + r : ref;
-            resolved = resolved | here;
-            r -= resolved ? 0u : q.len[k];
-        }
-        best_ref = ref;
     }
 }

@@ -40,16 +40,13 @@ enum ColdField {
 enum PoolTag { TAG_FREE = 0, TAG_TRACE_EXT = 1, TAG_TRACE_SHADOW = 2, TAG_MISS = 3, TAG_SHADE = 4, TAG_BSDF = 5, TAG_IDLE = 6 };
 enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_BSDF = 4, ST_COUNT = 5 };
 
-template <uint32_t POOL, bool PAIRS>
+template <uint32_t POOL>
 struct PoolLayout {
     static constexpr uint32_t kSlotsPerLane = (POOL + 63u) / 64u;
     static constexpr uint32_t kHotDwords = H_COUNT * POOL;
-    // scratch after the hot columns: the compaction list (64), or for PAIRS 64 u64 keys + two pair lists
-    // (the compaction list is dead once every lane has read its slot and shares the first pair list)
-    static constexpr uint32_t kListDwords = PAIRS ? 128u + 2u * RT_LIST_CAP : 64u;
+    static constexpr uint32_t kListDwords = 64u;
     static constexpr uint32_t kWaveLdsDwords = kHotDwords + kListDwords;
     static constexpr uint32_t kWaveColdDwords = C_COUNT * POOL;
-    static_assert(kHotDwords % 2u == 0u && kWaveLdsDwords % 2u == 0u, "u64 keys need 8-byte alignment");
 };
 
 RT_DEV uint32_t stage_of_tag(uint32_t tag)
@@ -61,10 +58,10 @@ RT_DEV uint32_t stage_of_tag(uint32_t tag)
 #ifndef RT_POOL_WAVES_PER_SIMD
 #define RT_POOL_WAVES_PER_SIMD 5
 #endif
-template <bool LDS, uint32_t POOL, bool PAIRS>
+template <bool LDS, uint32_t POOL>
 __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
 {
-    typedef PoolLayout<POOL, PAIRS> L;
+    typedef PoolLayout<POOL> L;
     const DevScene &sc = P.scene;
     if (LDS) stage_scene_lds(sc);
     const SceneView<LDS> S = make_view<LDS>(sc);
@@ -72,7 +69,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
     const uint32_t wave = threadIdx.x / RT_WAVE;
     uint32_t *const lds32 = reinterpret_cast<uint32_t *>(rt_smem + sc.lds_float4s);
     uint32_t *const W = lds32 + wave * L::kWaveLdsDwords; // this wave's hot columns
-    uint32_t *const list = W + L::kHotDwords + (PAIRS ? 128u : 0u);
+    uint32_t *const list = W + L::kHotDwords;
     uint32_t *const G = P.cold_state + (size_t)(blockIdx.x * (RT_BLOCK / RT_WAVE) + wave) * L::kWaveColdDwords; // cold columns
     const bool prune = (P.flags & RSRT_FLAG_PRUNE) != 0;
     const bool anyhit_shadow = !(P.flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
@@ -187,47 +184,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
                     if (lane + 64u * k < POOL && TAG_OF(lane + 64u * k) == TAG_FREE) SET_TAG(lane + 64u * k, TAG_IDLE);
             }
-        } else if (best == ST_TRACE && PAIRS) {
-            // ---------------- TRACE, wave-cooperative: each lane walks the boxes of its own ray and collects
-            // leaves; the primitives of all held leaves are tested by the whole wave (rt_device.h,
-            // test_leaves_as_a_wave).  ALL 64 lanes run this block: lanes without a ray still test pairs.
-            const uint32_t ct = on ? HOT(H_CT, slot) : (RT_END << 3);
-            const bool shadow = (ct & 7u) == TAG_TRACE_SHADOW;
-            const bool anyhit = shadow && anyhit_shadow;
-            const V3 o = on ? v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot)) : v3(0.0f, 0.0f, 0.0f);
-            const V3 d = on ? v3(HOTF(H_DX, slot), HOTF(H_DY, slot), HOTF(H_DZ, slot)) : v3(1.0f, 1.0f, 1.0f);
-            uint32_t cur = ct >> 3;
-            float best_t = on ? HOTF(H_T, slot) : 0.0f;
-            uint32_t best_ref = 0xffffffffu; // "not improved by this call": C_REF of an earlier call stays
-            const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-            const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
-            const uint32_t ebase = octant * sc.n_nodes;
-            unsigned long long *const keys = reinterpret_cast<unsigned long long *>(W + L::kHotDwords);
-            uint32_t *const tri_list = W + L::kHotDwords + 128u, *const oth_list = tri_list + RT_LIST_CAP;
-            __builtin_amdgcn_wave_barrier(); // every lane has read its slot from `list` (= tri_list) by now
-            for (uint32_t round = 0; round < P.trace_rounds; round++) {
-                LeafQueue q;
-                DBG_STAMP(27); // TRACE prologue (and, after the first round, the round's tail)
-                trace_collect(DBG_ARG S, ebase, octant, o, inv, prune, best_t, P.trace_budget, cur, q);
-                DBG_STAMP(23);
-                test_leaves_as_a_wave(DBG_ARG S, lane, o, d, q, keys, tri_list, oth_list, best_t, best_ref);
-                DBG_STAMP(24);
-                if (anyhit & (best_t < RT_INFINITY)) cur = RT_END; // the shadow query only wants to know whether anything is hit
-                if (__ballot(cur != RT_END) == 0ull) break;
-            }
-            if (on) {
-                SETH(H_T, slot, best_t);
-                if (!shadow && best_ref != 0xffffffffu) COLD(C_REF, slot) = best_ref;
-                if (cur == RT_END) {
-                    if (shadow) { n_shadow++; SET_TAG(slot, TAG_BSDF); } // H_T < INFINITY <=> occluded
-                    else { n_ext++; SET_TAG(slot, best_t < RT_INFINITY ? TAG_SHADE : TAG_MISS); }
-                } else {
-                    SET_CUR_TAG(slot, cur, ct & 7u);
-                }
-            }
         } else if (best == ST_TRACE) {
-            // ---------------- TRACE, in-lane (the A/B baseline, and the fallback for scenes whose leaves or
-            // record count do not fit the pair encoding): the slot's o / d ARE the ray to trace.
+            // ---------------- TRACE: cast_ray_bvh for extension and shadow rays together.  The slot's
+            // o / d ARE the ray to trace (SHADE already moved a shadow ray's origin to the hit point).
             if (on) {
                 const uint32_t ct = HOT(H_CT, slot);
                 const bool shadow = (ct & 7u) == TAG_TRACE_SHADOW;

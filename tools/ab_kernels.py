@@ -1,4 +1,4 @@
-"""Scratch: parity + timing of the kernel variants (RSRT_KERNEL=0..3) in one process, interleaved rounds."""
+"""Scratch: parity + timing of the kernel variants (RSRT_KERNEL=0..2) in one process, interleaved rounds."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -6,7 +6,7 @@ import numpy as np
 import oracle, util
 import rsoderh_raytracing_amd as R
 
-variants = [int(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else '0,1,2,3'.split(','))]
+variants = [int(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else '0,1,2'.split(','))]
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 env_small = R.Environment.synthetic(256, 128)
 for name, W, H, s, mb in [('house', 160, 90, 8, 8), ('default', 96, 64, 4, 10), ('suzanne', 96, 64, 4, 10)]:

@@ -16,7 +16,7 @@ for y, x in bad[:20]:
     print(x, y, imgs['0'][y, x], imgs['2'][y, x])
 # narrow down the sample index for the first few
 os.environ['RSRT_KERNEL'] = '0'; s0 = R.State.new(sc, env, 1920, 1080); s0.max_bounces = 8
-os.environ['RSRT_KERNEL'] = '2'; s2 = R.State.new(sc, env, 1920, 1080); s2.max_bounces = 8
+os.environ['RSRT_KERNEL'] = '1'; s2 = R.State.new(sc, env, 1920, 1080); s2.max_bounces = 8
 for y, x in bad[:5]:
     for k in range(256):
         s0.clear(); s0.render_range(k, 1); a = s0.download()[y, x]

@@ -24,13 +24,8 @@ print('  trace: outer trips/wave-invocation %.2f' % (c[14] / max(c[1], 1)))
 print('  descend loop: wave trips %.3e, lane trips %.3e -> efficiency %.1f%% of 64 lanes ; nodes/ray %.2f' % (c[10], c[11], 100 * c[11] / max(64 * c[10], 1), c[11] / rays))
 print('  leaf loop   : wave trips %.3e, lane trips %.3e -> efficiency %.1f%% ; prim tests/ray %.2f' % (c[12], c[13], 100 * c[13] / max(64 * c[12], 1), c[13] / rays))
 print('  per TRACE invocation: descend wave trips %.1f, leaf wave trips %.1f' % (c[10] / max(c[1], 1), c[12] / max(c[1], 1)))
-c[17] += c[23] + c[24] + c[27]  # the TRACE stage's inner stamps (wave-cooperative kernel)
 tot = sum(c[16:23])
 if tot:
     print('  wave-time shares (s_memtime, lane 0): ' + '  '.join('%s %.1f%%' % (n, 100 * c[16 + i] / tot) for i, n in enumerate(names)) +
           '  census %.1f%%  other %.1f%%' % (100 * c[22] / tot, 100 * c[21] / tot))
     print('  cycles per invocation: ' + '  '.join('%s %.0f' % (n, c[16 + i] / max(c[i], 1)) for i, n in enumerate(names)) + '  census %.0f' % (c[22] / max(sum(c[0:5]), 1)))
-if c[23]:
-    inv = max(c[1], 1)
-    print('  TRACE split, cycles per invocation: prologue %.0f  collect %.0f  leaves %.0f (triangle batches %.0f [%.1f], other batches %.0f [%.1f], expansion+merge %.0f, %.1f iterations)' % (
-        c[27] / inv, c[23] / inv, c[24] / inv, c[25] / inv, c[12] / inv, c[26] / inv, c[15] / inv, (c[24] - c[25] - c[26]) / inv, c[14] / inv))
