@@ -161,6 +161,13 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n_rays, const float *orig
  * tools/simd_efficiency.py); all zero in the product build. Cumulative since context creation. */
 rsrt_status rsrt_get_debug_counters(rsrt_context *ctx, uint64_t out[32]);
 
+/* Exhaustive device self-test of the numeric contract's one shortcut: the 3-instruction reciprocal used for
+ * 1/x (rt_math.h, rt_rcp) against the compiler's correctly rounded division, over all 2^32 f32 bit patterns
+ * (~0.1 s).  out[0] = inputs where the bits differ (must be 0), out[1] = inputs that took the short path,
+ * out[2] = of those, how many the bare v_rcp_f32 gets wrong (shows the comparison is live), out[3] = smallest
+ * failing bit pattern or UINT64_MAX. */
+rsrt_status rsrt_selftest_numerics(rsrt_context *ctx, uint64_t out[4]);
+
 /* Library / device description, for logs: "librsrt <version>; <device name>; <CUs> CUs". */
 const char *rsrt_describe(rsrt_context *ctx);
 

@@ -381,15 +381,19 @@ struct Env {
 // with 192 / 160 path slots per wave (160: five workgroups per CU fit in LDS).
 #define RT_N_VARIANTS 3
 static const uint32_t kVariantPool[RT_N_VARIANTS] = {0, 192, 160};
-static const void *variant_function(int kv, bool lds)
+static const void *variant_function(int kv, bool lds, bool typed)
 {
-    switch (kv * 2 + (lds ? 1 : 0)) {
-    case 0: return reinterpret_cast<const void *>(&rt_render_kernel<false>);
-    case 1: return reinterpret_cast<const void *>(&rt_render_kernel<true>);
-    case 2: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192>);
-    case 3: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192>);
-    case 4: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 160>);
-    default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 160>);
+    switch (kv * 4 + (lds ? 2 : 0) + (typed ? 1 : 0)) {
+    case 0: case 1: return reinterpret_cast<const void *>(&rt_render_kernel<false>);
+    case 2: case 3: return reinterpret_cast<const void *>(&rt_render_kernel<true>);
+    case 4: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192, false>);
+    case 5: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192, true>);
+    case 6: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192, false>);
+    case 7: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192, true>);
+    case 8: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 160, false>);
+    case 9: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 160, true>);
+    case 10: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 160, false>);
+    default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 160, true>);
     }
 }
 
@@ -427,8 +431,9 @@ struct rsrt_context {
     unsigned long long base_counts[3] = {0, 0, 0};
     uint32_t cum_launches = 0, base_launches = 0;
     std::vector<hipEvent_t> event_pool;
-    int blocks_per_cu[2][RT_N_VARIANTS] = {}; // [lds][kernel variant]
+    int blocks_per_cu[4][RT_N_VARIANTS] = {}; // [lds * 2 + typed][kernel variant]
     int kernel_variant = 2; // index into kVariantPool
+    bool typed_leaves = true; // use trace_threaded_typed where the scene allows it
     uint32_t trace_budget = 12; // traversal steps per TRACE invocation before a ray is re-queued
     unsigned long long debug_words[32] = {0};
 };
@@ -608,11 +613,12 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
         return RSRT_ERR_HIP;
     }
     for (int kv = 0; kv < RT_N_VARIANTS; kv++)
-        for (int lds = 0; lds < 2; lds++) (void)hipFuncSetAttribute(variant_function(kv, lds != 0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int m = 0; m < 4; m++) (void)hipFuncSetAttribute(variant_function(kv, (m & 2) != 0, (m & 1) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *kv = getenv("RSRT_KERNEL")) { // see kVariantPool
         int v = atoi(kv);
         if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
     }
+    if (const char *ty = getenv("RSRT_TYPED_LEAVES")) ctx->typed_leaves = atoi(ty) != 0; // 0: generic leaf loop even where the typed one applies (A/B)
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_cast_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
@@ -726,10 +732,22 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     std::vector<float4> img(n_f4);
     float4 *p = img.data();
     float4 *p_nodes = p;
+    bool typed_leaves = true;
+    for (uint32_t i = 0; i < n_nodes; i++) typed_leaves = typed_leaves && nodes[i].primitives_len <= 8;
     for (uint32_t i = 0; i < n_nodes; i++, p += 2) {
         const rsrt_bvh_node &nd = nodes[i];
         p[0] = f4(nd.bounds_min[0], nd.bounds_min[1], nd.bounds_min[2], u2f(nd.primitives_or_second_child_index));
-        p[1] = f4(nd.bounds_max[0], nd.bounds_max[1], nd.bounds_max[2], u2f(nd.primitives_len | (nd.split_axis << 16)));
+        uint32_t hi = nd.split_axis; // interior: split axis; leaf (when every leaf has <= 8 primitives): triangle mask | plane mask << 8
+        if (nd.primitives_len != 0) {
+            hi = 0;
+            if (typed_leaves)
+                for (uint32_t k = 0; k < nd.primitives_len; k++) {
+                    const uint32_t ty = primitives[nd.primitives_or_second_child_index + k].primitive_type;
+                    if (ty >= 2) hi |= 1u << k;
+                    else if (ty == 1) hi |= 1u << (8 + k);
+                }
+        }
+        p[1] = f4(nd.bounds_max[0], nd.bounds_max[1], nd.bounds_max[2], u2f(nd.primitives_len | (hi << 16)));
     }
     float4 *p_prims = p;
     for (uint32_t i = 0; i < n_primitives; i++, p += 4) {
@@ -771,6 +789,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.n_nodes = n_nodes; sc.n_prims = n_primitives; sc.n_tris = n_triangles; sc.n_materials = n_materials;
     sc.n_spheres = n_spheres; sc.n_planes = n_planes;
     sc.stack_entries = depth + 1;
+    sc.typed_leaves = typed_leaves ? 1u : 0u;
     const size_t stack_bytes = (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t);
     if (stack_bytes > 128 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh depth %u exceeds the supported traversal stack", depth);
     sc.lds_float4s = (n_f4 * sizeof(float4) <= 24 * 1024) ? (uint32_t)n_f4 : 0u; // LDS image only while it leaves room for the path pools
@@ -963,8 +982,9 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
                                 : scene_bytes + (size_t)(RT_BLOCK / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
-    const void *kfn = variant_function(kv, lds);
-    int &bpc = ctx->blocks_per_cu[lds ? 1 : 0][kv];
+    const bool typed = ctx->typed_leaves && P.scene.typed_leaves != 0;
+    const void *kfn = variant_function(kv, lds, typed);
+    int &bpc = ctx->blocks_per_cu[(lds ? 2 : 0) + (typed ? 1 : 0)][kv];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, RT_BLOCK, smem);
@@ -1053,6 +1073,48 @@ rsrt_status rsrt_get_stats(rsrt_context *ctx, rsrt_stats *out)
     rsrt_status st = collect_stats(ctx);
     if (st) return st;
     *out = ctx->stats;
+    return RSRT_OK;
+}
+
+// Exhaustive check of rt_rcp against the compiler's correctly rounded division, all 2^32 bit patterns.
+__global__ void rt_selftest_rcp_kernel(unsigned long long *out)
+{
+    unsigned long long bad = 0, raw_differs = 0, fast_path = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = as_f((uint32_t)i);
+        const float ref = 1.0f / x;
+        if (as_u(rt_rcp(x)) != as_u(ref)) {
+            bad++;
+            atomicMin(&out[3], (unsigned long long)i);
+        }
+        const uint32_t ex = ((uint32_t)i >> 23) & 0xffu;
+        if (ex - 2u < 251u) {
+            fast_path++;
+            if (as_u(__builtin_amdgcn_rcpf(x)) != as_u(ref)) raw_differs++; // sanity: the Newton step is doing something
+        }
+    }
+    atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], fast_path);
+    atomicAdd(&out[2], raw_differs);
+}
+
+rsrt_status rsrt_selftest_numerics(rsrt_context *ctx, uint64_t out[4])
+{
+    if (!ctx || !out) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    unsigned long long *d = nullptr, h[4] = {0, 0, 0, ~0ull};
+    HIP_TRY(ctx, hipMalloc(&d, sizeof h));
+    hipError_t e = hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rt_selftest_rcp_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, RSRT_ERR_HIP, "selftest: %s", hipGetErrorString(e));
+    for (int i = 0; i < 4; i++) out[i] = h[i];
     return RSRT_OK;
 }
 

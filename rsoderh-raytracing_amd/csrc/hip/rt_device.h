@@ -55,6 +55,7 @@ struct DevScene {
     uint32_t n_nodes, n_prims, n_tris, n_materials, n_spheres, n_planes;
     uint32_t stack_entries;    // per-lane traversal stack entries (tree depth + 1)
     uint32_t lds_float4s;      // float4 count of the LDS image (0 = scene stays in global memory)
+    uint32_t typed_leaves;     // no leaf has more than 8 primitives: leaf node words carry triangle / plane masks (trace_threaded_typed)
 };
 
 struct DevEnv {
@@ -168,7 +169,7 @@ RT_DEV float triangle_t(V3 o, V3 d, V3 a, V3 e0, V3 e1, float &u, float &v)
     const V3 p0 = cross(op, e0);
     const V3 p1 = cross(d, e1);
     const float det = dot(e0, p1);
-    const float inv = 1.0f / det;
+    const float inv = rt_rcp(det);
     u = dot(op, p1) * inv;
     v = dot(d, p0) * inv;
     const float t = dot(e1, p0) * inv;
@@ -268,7 +269,7 @@ RT_DEV float test_record(const View &S, uint32_t rec, uint32_t src, V3 o, V3 d, 
 template <bool ANYHIT, class View>
 RT_DEV void trace_bvh(const View &S, V3 o, V3 d, bool prune, uint32_t *stack, uint32_t stride, Hit &h)
 {
-    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
     h.t = RT_INFINITY;
     h.ref = 0;
     h.src = SRC_BVH;
@@ -468,7 +469,7 @@ RT_DEV float lambda_ggx(float ndv, float alpha) // :1014-1020
     float ndv2 = ndv * ndv;
     return (rsrt_sqrtf(1.0f + alpha * alpha * (1.0f - ndv2) / ndv2) - 1.0f) / 2.0f;
 }
-RT_DEV float g1_ggx(float ndv, float alpha) { return 1.0f / (1.0f + lambda_ggx(ndv, alpha)); } // :1026-1028
+RT_DEV float g1_ggx(float ndv, float alpha) { return rt_rcp(1.0f + lambda_ggx(ndv, alpha)); } // :1026-1028
 RT_DEV V3 f_schlick(V3 f0, float c) // :1045-1051
 {
     float x = 1.0f - saturate(c);
@@ -609,7 +610,7 @@ RT_DEV float power_heuristic(float a, float b) // :1206-1210
 template <class View>
 RT_DEV void trace_ww(DBG_DECL const View &S, V3 o, V3 d, bool prune, bool anyhit, uint32_t *stack, uint32_t stride, Hit &h)
 {
-    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
     h.t = RT_INFINITY;
     h.ref = 0;
     h.src = SRC_BVH;
@@ -742,7 +743,7 @@ template <class View>
 RT_DEV void trace_threaded(DBG_DECL const View &S, uint32_t n_nodes, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget,
                            uint32_t &cur, Hit &h)
 {
-    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
     const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
     const uint32_t ebase = octant * n_nodes;
     uint32_t steps = 0;
@@ -806,3 +807,118 @@ RT_DEV void trace_threaded(DBG_DECL const View &S, uint32_t n_nodes, V3 o, V3 d,
         }
     }
 }
+
+// ------------------------------------------------------------------ typed leaf loops
+// In trace_threaded's leaf loop the lanes of a wave hold primitives of all three types, so nearly every
+// trip runs the triangle, the sphere AND the plane routine (~190 VALU) for ~27 tests.  When no leaf has
+// more than 8 primitives (the reference's builder stops at 5) rsrt_upload_scene packs a triangle mask
+// and a plane mask into the leaf's node word; a lane then ORs the masks of the leaves it holds into
+// three 8-bit-per-leaf masks and the wave runs three HOMOGENEOUS loops — triangles, planes, spheres —
+// each lane walking its own mask with ctz.  Testing out of depth-first order needs the tie rule spelled
+// out: position p (leaf * 8 + index) IS the depth-first order within the round, the incumbent of earlier
+// rounds counts as position -1, and of equal t the earlier position wins — exactly what the
+// reference's strict `<` in visiting order decides.  Triangles go first, in order, so plain `<` does it
+// there.
+RT_DEV uint32_t take_lowest(uint32_t &mask)
+{
+    const uint32_t p = (uint32_t)__builtin_ctz(mask);
+    mask &= mask - 1u;
+    return p;
+}
+
+template <class View>
+RT_DEV void trace_threaded_typed(DBG_DECL const View &S, uint32_t n_nodes, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t &cur,
+                                 Hit &h)
+{
+    static_assert(RT_LEAFQ <= 4, "one byte of each 32-bit mask per held leaf");
+    const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+    const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    const uint32_t ebase = octant * n_nodes;
+    uint32_t steps = 0;
+    while (cur != RT_END && steps < budget) {
+        DBG_WAVE_TICK(14);
+        uint32_t qi[RT_LEAFQ];
+        uint32_t nq = 0, all_m = 0, tri_m = 0, pl_m = 0;
+#pragma unroll
+        for (int j = 0; j < RT_LEAFQ; j++) qi[j] = 0u;
+        while (cur != RT_END && nq < RT_LEAFQ) {
+            DBG_WAVE_TICK(10);
+            DBG_ADD(11, 1);
+            steps++;
+            const float4 n0 = S.node(2u * cur), n1 = S.node(2u * cur + 1u);
+            const uint32_t esc = S.esc(ebase + cur);
+            float t_0;
+            bool inside = slab_test(n0, n1, o, inv, t_0);
+            inside = inside & !(prune & (t_0 > h.t));
+            const uint32_t idx = as_u(n0.w), la = as_u(n1.w);
+            const uint32_t len = la & 0xffffu, hi = la >> 16; // hi: split axis (interior) / triangle mask | plane mask << 8 (leaf)
+            const bool descend = inside & (len == 0u);
+            const uint32_t near_child = ((octant >> (hi & 3u)) & 1u) ? idx : cur + 1u;
+            if (inside & (len != 0u)) {
+#pragma unroll
+                for (int j = 0; j < RT_LEAFQ; j++) qi[j] = (nq == (uint32_t)j) ? idx : qi[j];
+                const uint32_t sh = 8u * nq;
+                all_m |= ((1u << len) - 1u) << sh;
+                tri_m |= (hi & 0xffu) << sh;
+                pl_m |= (hi >> 8) << sh;
+                steps += len;
+                nq++;
+            }
+            cur = descend ? near_child : esc;
+        }
+        uint32_t sp_m = all_m & ~(tri_m | pl_m);
+        uint32_t best_p = 0xffffffffu; // position of the round's best so far; the incumbent is "before everything"
+        // ---- triangles, in visiting order
+        while (tri_m != 0u) {
+            DBG_WAVE_TICK(12);
+            DBG_ADD(13, 1);
+            const uint32_t p = take_lowest(tri_m);
+            uint32_t base = qi[0];
+#pragma unroll
+            for (int j = 1; j < RT_LEAFQ; j++) base = ((p >> 3) == (uint32_t)j) ? qi[j] : base;
+            const uint32_t rec = base + (p & 7u);
+            const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u);
+            float u, v;
+            const float t = triangle_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), u, v);
+            const bool better = (t >= 0.0f) & (t < h.t);
+            h.t = better ? t : h.t;
+            h.ref = better ? rec : h.ref;
+            best_p = better ? p : best_p;
+            if (better & anyhit) { cur = RT_END; tri_m = pl_m = sp_m = 0u; }
+        }
+        // ---- planes, then spheres: out of order, so equal t is decided by position
+        while (pl_m != 0u) {
+            DBG_WAVE_TICK(15);
+            DBG_ADD(13, 1);
+            const uint32_t p = take_lowest(pl_m);
+            uint32_t base = qi[0];
+#pragma unroll
+            for (int j = 1; j < RT_LEAFQ; j++) base = ((p >> 3) == (uint32_t)j) ? qi[j] : base;
+            const uint32_t rec = base + (p & 7u);
+            const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u), r3 = S.prim(4u * rec + 3u);
+            const float t = plane_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), v3(r3.x, r3.y, r3.z));
+            const bool better = (t >= 0.0f) & ((t < h.t) | ((t == h.t) & (p < best_p) & (best_p != 0xffffffffu)));
+            h.t = better ? t : h.t;
+            h.ref = better ? rec : h.ref;
+            best_p = better ? p : best_p;
+            if (better & anyhit) { cur = RT_END; pl_m = sp_m = 0u; }
+        }
+        while (sp_m != 0u) {
+            DBG_WAVE_TICK(28);
+            DBG_ADD(13, 1);
+            const uint32_t p = take_lowest(sp_m);
+            uint32_t base = qi[0];
+#pragma unroll
+            for (int j = 1; j < RT_LEAFQ; j++) base = ((p >> 3) == (uint32_t)j) ? qi[j] : base;
+            const uint32_t rec = base + (p & 7u);
+            const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u);
+            const float t = sphere_t(o, d, v3(r0.x, r0.y, r0.z), r1.y);
+            const bool better = (t >= 0.0f) & ((t < h.t) | ((t == h.t) & (p < best_p) & (best_p != 0xffffffffu)));
+            h.t = better ? t : h.t;
+            h.ref = better ? rec : h.ref;
+            best_p = better ? p : best_p;
+            if (better & anyhit) { cur = RT_END; sp_m = 0u; }
+        }
+    }
+}
+

@@ -6,6 +6,8 @@
 //  * the only fused multiply-adds are the explicit fmaf() calls in dot / dot2 / cross /
 //    mat3_mul / madd below;
 //  * normalize(v) = v * (1/sqrt(dot(v,v))), inverse_sqrt(x) = 1/sqrt(x), length = sqrt(dot);
+//  * rt_rcp(x) IS the correctly rounded 1.0f / x, computed in 3 instructions instead of the compiler's 11
+//    where that is exhaustively verified to give the same bits (rsrt_selftest_numerics);
 //  * fmax_/fmin_ are the compare-select forms (a<b?b:a / b<a?b:a), NaN handling included;
 //  * transcendental functions come from include/rsrt_detmath.h.
 #pragma once
@@ -50,9 +52,30 @@ RT_DEV V3 mat3_mul(V3 c0, V3 c1, V3 c2, V3 v)
               __builtin_fmaf(c2.y, v.z, __builtin_fmaf(c1.y, v.y, c0.y * v.x)),
               __builtin_fmaf(c2.z, v.z, __builtin_fmaf(c1.z, v.y, c0.z * v.x))};
 }
+
+RT_DEV float as_f(uint32_t u) { return __uint_as_float(u); }
+RT_DEV uint32_t as_u(float f) { return __float_as_uint(f); }
+
+// 1.0f / x, correctly rounded.  For an exponent field in [2, 252] (|x| in [2^-125, 2^126): neither x nor
+// 1/x is subnormal) v_rcp_f32 plus ONE Newton step in fma arithmetic equals the IEEE quotient for every
+// one of the 2 * 251 * 2^23 inputs — checked exhaustively on the device by rsrt_selftest_numerics, which
+// tests/test_gpu_parity.py runs.  Everything else (zeros, subnormals, huge, inf, NaN) takes the
+// compiler's full division; the empty asm keeps that path a branch instead of a select of both.
+RT_DEV float rt_rcp(float x)
+{
+    const uint32_t ex = (as_u(x) >> 23) & 0xffu;
+    if (ex - 2u < 251u) {
+        const float r0 = __builtin_amdgcn_rcpf(x);
+        const float e = __builtin_fmaf(-x, r0, 1.0f);
+        return __builtin_fmaf(e, r0, r0);
+    }
+    asm volatile("; rt_rcp: full division");
+    return 1.0f / x;
+}
+
 RT_DEV float length(V3 a) { return rsrt_sqrtf(dot(a, a)); }
-RT_DEV V3 normalize(V3 a) { return a * (1.0f / rsrt_sqrtf(dot(a, a))); }
-RT_DEV float inverse_sqrt(float x) { return 1.0f / rsrt_sqrtf(x); }
+RT_DEV V3 normalize(V3 a) { return a * rt_rcp(rsrt_sqrtf(dot(a, a))); }
+RT_DEV float inverse_sqrt(float x) { return rt_rcp(rsrt_sqrtf(x)); }
 
 // WGSL u32(f32) as naga emits it: NaN / negative -> 0, clamp at the largest f32 below 2^32
 RT_DEV uint32_t f2u(float x)
@@ -62,5 +85,3 @@ RT_DEV uint32_t f2u(float x)
     return (uint32_t)x;
 }
 
-RT_DEV float as_f(uint32_t u) { return __uint_as_float(u); }
-RT_DEV uint32_t as_u(float f) { return __float_as_uint(f); }

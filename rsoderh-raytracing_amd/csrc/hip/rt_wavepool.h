@@ -58,7 +58,7 @@ RT_DEV uint32_t stage_of_tag(uint32_t tag)
 #ifndef RT_POOL_WAVES_PER_SIMD
 #define RT_POOL_WAVES_PER_SIMD 5
 #endif
-template <bool LDS, uint32_t POOL>
+template <bool LDS, uint32_t POOL, bool TYPED>
 __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
 {
     typedef PoolLayout<POOL> L;
@@ -198,7 +198,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 h.src = SRC_BVH;
                 h.t = HOTF(H_T, slot); h.ref = 0; h.u = h.v = 0.0f; // ref of an earlier call stays in the cold column unless beaten
                 const float t_in = h.t;
-                trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
+                if (TYPED) trace_threaded_typed(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
+                else trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
                 const bool done = cur == RT_END;
                 SETH(H_T, slot, h.t);
                 if (!shadow && h.t < t_in) COLD(C_REF, slot) = h.ref; // this call found a closer hit

@@ -22,7 +22,8 @@ FLAG_PRUNE = 2                # opt-in t-pruning; NOT exactly result-preserving 
 _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "rsrt_upload_scene",
             "rsrt_upload_environment", "rsrt_set_partition", "rsrt_accumulator_resize", "rsrt_accumulator_bind",
             "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_render",
-            "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters", "rsrt_display_srgb8"]
+            "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters", "rsrt_display_srgb8",
+            "rsrt_selftest_numerics"]
 
 
 class RsrtError(RuntimeError):
@@ -73,6 +74,7 @@ def lib():
         L.rsrt_synchronize.argtypes = [C.c_void_p]
         L.rsrt_get_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.rsrt_get_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.rsrt_selftest_numerics.argtypes = [C.c_void_p, C.c_void_p]
         L.rsrt_cast_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib = L
     return _lib
@@ -227,6 +229,12 @@ class State:
         out = np.zeros(32, np.uint64)
         self._check(self._L.rsrt_get_debug_counters(self._ctx, _p(out)), "rsrt_get_debug_counters")
         return out
+
+    def selftest_numerics(self):
+        """Exhaustive device check of the short reciprocal (all 2^32 inputs): dict of the four words of rsrt_selftest_numerics."""
+        out = np.zeros(4, np.uint64)
+        self._check(self._L.rsrt_selftest_numerics(self._ctx, _p(out)), "rsrt_selftest_numerics")
+        return {"mismatches": int(out[0]), "short_path_inputs": int(out[1]), "bare_rcp_wrong": int(out[2]), "first_bad": int(out[3])}
 
     def cast_rays(self, origins, directions, mode=0, flags=0):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)

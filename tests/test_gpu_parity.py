@@ -351,3 +351,15 @@ def test_invalid_input_is_rejected_not_launched(big_env):
     with pytest.raises(RsrtError, match="environment 0 not uploaded"):
         st.render_range(0, 1)
     st.close()
+
+
+def test_short_reciprocal_is_the_ieee_quotient_for_every_input(big_env):
+    """rt_rcp (rt_math.h): v_rcp_f32 + one Newton step replaces the 11-instruction division where the exponent
+    allows it.  The device compares it with `1.0f / x` for all 2^32 bit patterns."""
+    sc = R.Scene.load_toml(util.scene_path("cube"))
+    st = R.State.new(sc, big_env, 16, 16)
+    r = st.selftest_numerics()
+    st.close()
+    assert r["mismatches"] == 0, hex(r["first_bad"])
+    assert r["short_path_inputs"] == 2 * 251 * 2 ** 23
+    assert r["bare_rcp_wrong"] > 0  # the comparison is live: the bare instruction is NOT correctly rounded

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Scratch: build librsrt variants with different compiler flags HERE (no GPU needed), then time each on the
-# GPU box:  tools/flag_sweep.sh build   (local)  /  tools/flag_sweep.sh run [kernel] (inside gpurun)
+# GPU box:  tools/flag_sweep.sh build   (local)  /  tools/flag_sweep.sh run [kernel [KNOB values]] (inside gpurun)
 # Variants live under build_exp/ (git-ignored, travels with gpurun).
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
@@ -15,9 +15,9 @@ if [ "$1" = build ]; then
     i=$((i+1))
   done
 else
-  K="${2:-1}"
+  K="${2:-2}"; KNOB="${3:-RSRT_DUMMY}"; VALS="${4:-0}"
   for so in "$ROOT"/build_exp/v*.so; do
     echo "== $(basename $so): $(grep "^$(basename $so .so):" "$ROOT/build_exp/index.txt")"
-    RSRT_LIB="$so" python "$ROOT/tools/knob_sweep.py" RSRT_DUMMY 0 "$K" 64 | tail -2
+    RSRT_LIB="$so" python "$ROOT/tools/knob_sweep.py" "$KNOB" "$VALS" "$K" 64 | grep "round 2"
   done
 fi

@@ -29,3 +29,6 @@ if tot:
     print('  wave-time shares (s_memtime, lane 0): ' + '  '.join('%s %.1f%%' % (n, 100 * c[16 + i] / tot) for i, n in enumerate(names)) +
           '  census %.1f%%  other %.1f%%' % (100 * c[22] / tot, 100 * c[21] / tot))
     print('  cycles per invocation: ' + '  '.join('%s %.0f' % (n, c[16 + i] / max(c[i], 1)) for i, n in enumerate(names)) + '  census %.0f' % (c[22] / max(sum(c[0:5]), 1)))
+if c[15] or c[28]:
+    inv = max(c[1], 1)
+    print('  typed leaf loops per TRACE invocation: triangle trips %.2f, plane trips %.2f, sphere trips %.2f' % (c[12] / inv, c[15] / inv, c[28] / inv))
