@@ -731,7 +731,7 @@ RT_DEV bool slab_test(float4 n0, float4 n1, V3 o, V3 inv, float &t_entry)
 // any lane (h carries the best hit so far).
 #define RT_END 0x1fffffffu // 29 bits: the pool kernel keeps cursor and stage tag in one word
 #ifndef RT_LEAFQ
-#define RT_LEAFQ 3
+#define RT_LEAFQ 4
 #endif
 // A lane keeps descending until it holds RT_LEAFQ leaves (or its traversal ends) before the wave
 // switches to primitive testing: fewer and better-filled rounds than one leaf per round.  Leaves are
