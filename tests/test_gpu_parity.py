@@ -78,17 +78,19 @@ def test_matches_oracle_live(name, w, h, spp, mb, big_env):
     assert (st["paths"], st["ext_rays"], st["shadow_rays"]) == (ost["paths"], ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2"])
-def test_every_kernel_variant_is_bit_exact(variant, big_env, monkeypatch):
-    """RSRT_KERNEL: 0 = lockstep megakernel, 1/2 = stage-scheduled wave-pool kernel (192/160 slots per wave).
+@pytest.mark.parametrize("variant,typed", [("0", "1"), ("1", "1"), ("2", "1"), ("2", "0")])
+def test_every_kernel_variant_is_bit_exact(variant, typed, big_env, monkeypatch):
+    """RSRT_KERNEL: 0 = lockstep megakernel, 1/2 = stage-scheduled wave-pool kernel (192/160 slots per wave);
+    RSRT_TYPED_LEAVES=0: the generic in-order leaf loop instead of the per-type loops.
     Scheduling differs, the per-path arithmetic does not: all must give the oracle's bits."""
     monkeypatch.setenv("RSRT_KERNEL", variant)
+    monkeypatch.setenv("RSRT_TYPED_LEAVES", typed)
     for name, w, h, spp, mb in [("house", 150, 70, 6, 8), ("suzanne", 64, 48, 3, 10)]:
         sc = R.Scene.load_toml(util.scene_path(name))
         ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), w, h, 0, spp, mb)
         for flags in (0, R.state.FLAG_REFERENCE_TRAVERSAL):
             img, st = gpu_render(sc, big_env, w, h, 0, spp, mb, flags)
-            assert np.array_equal(util.bits(img), util.bits(ref)), (name, variant, flags)
+            assert np.array_equal(util.bits(img), util.bits(ref)), (name, variant, typed, flags)
             assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 

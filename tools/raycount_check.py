@@ -8,7 +8,7 @@ sc = R.Scene.load_toml(util.scene_path('house'))
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(env), sc.camera_uniform().view(oracle.CAMERA), 1920, 1080, 0, spp, 8, fast=True)
 print('oracle', ost['paths'], ost['ext_rays'], ost['shadow_rays'])
-for v in '0', '2':
+for v in '1', '2':
     os.environ['RSRT_KERNEL'] = v
     st = R.State.new(sc, env, 1920, 1080); st.max_bounces = 8
     st.render_range(0, spp); img = st.download(); g = st.stats()
