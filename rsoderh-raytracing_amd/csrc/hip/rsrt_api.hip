@@ -66,12 +66,13 @@ __device__ __forceinline__ SceneView<true> make_view<true>(const DevScene &sc)
     v.o_mats = v.o_trin + 3u * sc.n_tris;
     v.o_fbs = v.o_mats + 4u * sc.n_materials;
     v.o_fbp = v.o_fbs + 4u * sc.n_spheres;
+    v.o_flat = v.o_fbp + 4u * sc.n_planes;
     return v;
 }
 template <>
 __device__ __forceinline__ SceneView<false> make_view<false>(const DevScene &sc)
 {
-    return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.escape};
+    return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.escape, sc.flat_leaves};
 }
 
 // Copies the scene image into LDS (the arrays are contiguous in one device allocation, in the order
@@ -381,20 +382,20 @@ struct Env {
 // with 192 / 160 path slots per wave (160: five workgroups per CU fit in LDS).
 #define RT_N_VARIANTS 3
 static const uint32_t kVariantPool[RT_N_VARIANTS] = {0, 192, 160};
-static const void *variant_function(int kv, bool lds, bool typed)
+template <bool LDS, uint32_t POOL>
+static const void *pool_function(int trav)
 {
-    switch (kv * 4 + (lds ? 2 : 0) + (typed ? 1 : 0)) {
-    case 0: case 1: return reinterpret_cast<const void *>(&rt_render_kernel<false>);
-    case 2: case 3: return reinterpret_cast<const void *>(&rt_render_kernel<true>);
-    case 4: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192, false>);
-    case 5: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 192, true>);
-    case 6: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192, false>);
-    case 7: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 192, true>);
-    case 8: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 160, false>);
-    case 9: return reinterpret_cast<const void *>(&rt_render_pool_kernel<false, 160, true>);
-    case 10: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 160, false>);
-    default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<true, 160, true>);
+    switch (trav) {
+    case 0: return reinterpret_cast<const void *>(&rt_render_pool_kernel<LDS, POOL, 0>);
+    case 1: return reinterpret_cast<const void *>(&rt_render_pool_kernel<LDS, POOL, 1>);
+    default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<LDS, POOL, 2>);
     }
+}
+static const void *variant_function(int kv, bool lds, int trav)
+{
+    if (kv == 0) return lds ? reinterpret_cast<const void *>(&rt_render_kernel<true>) : reinterpret_cast<const void *>(&rt_render_kernel<false>);
+    if (kv == 1) return lds ? pool_function<true, 192>(trav) : pool_function<false, 192>(trav);
+    return lds ? pool_function<true, 160>(trav) : pool_function<false, 160>(trav);
 }
 
 struct rsrt_context {
@@ -431,9 +432,9 @@ struct rsrt_context {
     unsigned long long base_counts[3] = {0, 0, 0};
     uint32_t cum_launches = 0, base_launches = 0;
     std::vector<hipEvent_t> event_pool;
-    int blocks_per_cu[4][RT_N_VARIANTS] = {}; // [lds * 2 + typed][kernel variant]
+    int blocks_per_cu[6][RT_N_VARIANTS] = {}; // [lds * 3 + traversal][kernel variant]
     int kernel_variant = 2; // index into kVariantPool
-    bool typed_leaves = true; // use trace_threaded_typed where the scene allows it
+    int max_traversal = 2; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
     uint32_t trace_budget = 12; // traversal steps per TRACE invocation before a ray is re-queued
     unsigned long long debug_words[32] = {0};
 };
@@ -613,12 +614,12 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
         return RSRT_ERR_HIP;
     }
     for (int kv = 0; kv < RT_N_VARIANTS; kv++)
-        for (int m = 0; m < 4; m++) (void)hipFuncSetAttribute(variant_function(kv, (m & 2) != 0, (m & 1) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int m = 0; m < 6; m++) (void)hipFuncSetAttribute(variant_function(kv, m >= 3, m % 3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *kv = getenv("RSRT_KERNEL")) { // see kVariantPool
         int v = atoi(kv);
         if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
     }
-    if (const char *ty = getenv("RSRT_TYPED_LEAVES")) ctx->typed_leaves = atoi(ty) != 0; // 0: generic leaf loop even where the typed one applies (A/B)
+    if (const char *ty = getenv("RSRT_TRAVERSAL")) ctx->max_traversal = atoi(ty); // cap: 0 generic tree walk, 1 typed leaf loops, 2 flat small-scene loop (A/B)
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_cast_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
@@ -727,9 +728,48 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         }
     }
     const size_t esc_f4 = (8ull * n_nodes + 3) / 4;
+    // ---- flat small-scene traversal (rt_device.h, trace_flat): leaf list, record masks, per-octant visiting ranks
+    std::vector<uint32_t> leaf_nodes;
+    bool flat_ok = n_primitives <= 64;
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        const rsrt_bvh_node &nd = nodes[i];
+        if (nd.primitives_len != 0) { leaf_nodes.push_back(i); continue; }
+        for (uint32_t c : {i + 1u, nd.primitives_or_second_child_index}) // every child box inside its parent's
+            for (int k = 0; k < 3; k++)
+                flat_ok = flat_ok && nodes[c].bounds_min[k] >= nd.bounds_min[k] && nodes[c].bounds_max[k] <= nd.bounds_max[k];
+    }
+    std::vector<uint32_t> flat_rank(8 * 16, 0u);
+    uint64_t tri_mask = 0, plane_mask = 0;
+    if (flat_ok) {
+        for (uint32_t p = 0; p < n_primitives; p++) {
+            if (primitives[p].primitive_type >= 2) tri_mask |= 1ull << p;
+            else if (primitives[p].primitive_type == 1) plane_mask |= 1ull << p;
+        }
+        for (uint32_t q = 0; q < 8; q++) { // the reference's near-child-first walk for this sign octant, every box "hit"
+            std::vector<uint32_t> st{0u};
+            uint32_t pos = 0;
+            while (!st.empty()) {
+                const uint32_t i = st.back();
+                st.pop_back();
+                const rsrt_bvh_node &nd = nodes[i];
+                if (nd.primitives_len != 0) {
+                    for (uint32_t k = 0; k < nd.primitives_len; k++, pos++) {
+                        const uint32_t rec = nd.primitives_or_second_child_index + k;
+                        flat_rank[q * 16 + (rec >> 2)] |= pos << (8 * (rec & 3));
+                    }
+                } else {
+                    const bool far_first = (q >> nd.split_axis) & 1u;
+                    const uint32_t first = i + 1, second = nd.primitives_or_second_child_index;
+                    st.push_back(far_first ? first : second); // far child: visited after the near one
+                    st.push_back(far_first ? second : first);
+                }
+            }
+        }
+    }
+    const size_t flat_f4 = flat_ok ? 2 * leaf_nodes.size() : 0, rank_f4 = flat_ok ? 32 : 0;
     // ---- build the device image: nodes | prims | escape links | tri normals | materials | fb spheres | fb planes
-    const size_t n_f4 = 2ull * n_nodes + 4ull * n_primitives + 3ull * n_triangles + 4ull * n_materials + 4ull * n_spheres + 4ull * n_planes + esc_f4;
-    std::vector<float4> img(n_f4);
+    const size_t n_f4 = 2ull * n_nodes + 4ull * n_primitives + 3ull * n_triangles + 4ull * n_materials + 4ull * n_spheres + 4ull * n_planes + esc_f4 + flat_f4;
+    std::vector<float4> img(n_f4 + rank_f4); // the rank table follows the LDS image
     float4 *p = img.data();
     float4 *p_nodes = p;
     bool typed_leaves = true;
@@ -772,12 +812,23 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     for (uint32_t i = 0; i < n_spheres; i++, p += 4) make_sphere_record(spheres[i], p);
     float4 *p_fbp = p;
     for (uint32_t i = 0; i < n_planes; i++, p += 4) make_plane_record(planes[i], p);
+    float4 *p_flat = p;
+    if (flat_ok) {
+        for (uint32_t i : leaf_nodes) {
+            const rsrt_bvh_node &nd = nodes[i];
+            const uint64_t lm = (nd.primitives_len >= 64 ? ~0ull : ((1ull << nd.primitives_len) - 1ull)) << nd.primitives_or_second_child_index;
+            p[0] = f4(nd.bounds_min[0], nd.bounds_min[1], nd.bounds_min[2], u2f((uint32_t)lm));
+            p[1] = f4(nd.bounds_max[0], nd.bounds_max[1], nd.bounds_max[2], u2f((uint32_t)(lm >> 32)));
+            p += 2;
+        }
+        memcpy(p, flat_rank.data(), flat_rank.size() * sizeof(uint32_t));
+    }
 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->scene_blob) { (void)hipFree(ctx->scene_blob); ctx->scene_blob = nullptr; }
     ctx->scene_ready = false;
-    HIP_TRY(ctx, hipMalloc(&ctx->scene_blob, n_f4 * sizeof(float4)));
-    HIP_TRY(ctx, hipMemcpy(ctx->scene_blob, img.data(), n_f4 * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc(&ctx->scene_blob, img.size() * sizeof(float4)));
+    HIP_TRY(ctx, hipMemcpy(ctx->scene_blob, img.data(), img.size() * sizeof(float4), hipMemcpyHostToDevice));
     DevScene &sc = ctx->scene;
     sc.nodes = ctx->scene_blob + (p_nodes - img.data());
     sc.prims = ctx->scene_blob + (p_prims - img.data());
@@ -786,6 +837,12 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.fb_spheres = ctx->scene_blob + (p_fbs - img.data());
     sc.fb_planes = ctx->scene_blob + (p_fbp - img.data());
     sc.escape = ctx->scene_blob + (p_esc - img.data());
+    sc.flat_leaves = ctx->scene_blob + (p_flat - img.data());
+    sc.flat_rank = reinterpret_cast<const uint32_t *>(ctx->scene_blob + n_f4);
+    sc.flat_ok = flat_ok ? 1u : 0u;
+    sc.n_leaves = (uint32_t)leaf_nodes.size();
+    sc.tri_mask_lo = (uint32_t)tri_mask; sc.tri_mask_hi = (uint32_t)(tri_mask >> 32);
+    sc.plane_mask_lo = (uint32_t)plane_mask; sc.plane_mask_hi = (uint32_t)(plane_mask >> 32);
     sc.n_nodes = n_nodes; sc.n_prims = n_primitives; sc.n_tris = n_triangles; sc.n_materials = n_materials;
     sc.n_spheres = n_spheres; sc.n_planes = n_planes;
     sc.stack_entries = depth + 1;
@@ -982,9 +1039,9 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
                                 : scene_bytes + (size_t)(RT_BLOCK / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
-    const bool typed = ctx->typed_leaves && P.scene.typed_leaves != 0;
-    const void *kfn = variant_function(kv, lds, typed);
-    int &bpc = ctx->blocks_per_cu[(lds ? 2 : 0) + (typed ? 1 : 0)][kv];
+    const int trav = (ctx->max_traversal >= 2 && P.scene.flat_ok) ? 2 : ((ctx->max_traversal >= 1 && P.scene.typed_leaves) ? 1 : 0);
+    const void *kfn = variant_function(kv, lds, trav);
+    int &bpc = ctx->blocks_per_cu[(lds ? 3 : 0) + trav][kv];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, RT_BLOCK, smem);

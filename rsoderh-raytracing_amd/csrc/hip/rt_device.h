@@ -52,10 +52,15 @@ struct DevScene {
     const float4 *fb_spheres;  // 4 per sphere, scene order (cast_ray's brute-force loop)
     const float4 *fb_planes;   // 4 per plane
     const float4 *escape;      // 8 octants x n_nodes u32 'next node when this subtree is done', packed 4 per float4
+    const float4 *flat_leaves; // 2 per leaf: {min.xyz, record mask lo}{max.xyz, record mask hi} (trace_flat)
     uint32_t n_nodes, n_prims, n_tris, n_materials, n_spheres, n_planes;
     uint32_t stack_entries;    // per-lane traversal stack entries (tree depth + 1)
     uint32_t lds_float4s;      // float4 count of the LDS image (0 = scene stays in global memory)
     uint32_t typed_leaves;     // no leaf has more than 8 primitives: leaf node words carry triangle / plane masks (trace_threaded_typed)
+    // flat small-scene traversal (trace_flat): at most 64 primitive records, every child box inside its parent's
+    uint32_t flat_ok, n_leaves;
+    uint32_t tri_mask_lo, tri_mask_hi, plane_mask_lo, plane_mask_hi; // which records are triangles / planes
+    const uint32_t *flat_rank; // [8 octants][16]: byte p = position of record p in that octant's depth-first visiting order
 };
 
 struct DevEnv {
@@ -76,8 +81,9 @@ extern __shared__ float4 rt_smem[];
 
 template <>
 struct SceneView<true> {
-    uint32_t o_nodes, o_prims, o_esc, o_trin, o_mats, o_fbs, o_fbp;
+    uint32_t o_nodes, o_prims, o_esc, o_trin, o_mats, o_fbs, o_fbp, o_flat;
     RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
+    RT_DEV float4 flat(uint32_t i) const { return rt_smem[o_flat + i]; }
     RT_DEV float4 prim(uint32_t i) const { return rt_smem[o_prims + i]; }
     RT_DEV float4 trin(uint32_t i) const { return rt_smem[o_trin + i]; }
     RT_DEV float4 mat(uint32_t i) const { return rt_smem[o_mats + i]; }
@@ -92,8 +98,9 @@ struct SceneView<true> {
 };
 template <>
 struct SceneView<false> {
-    const float4 *nodes, *prims, *tri_normals, *materials, *fb_spheres, *fb_planes, *escape;
+    const float4 *nodes, *prims, *tri_normals, *materials, *fb_spheres, *fb_planes, *escape, *flat_leaves;
     RT_DEV float4 node(uint32_t i) const { return nodes[i]; }
+    RT_DEV float4 flat(uint32_t i) const { return flat_leaves[i]; }
     RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
     RT_DEV float4 trin(uint32_t i) const { return tri_normals[i]; }
     RT_DEV float4 mat(uint32_t i) const { return materials[i]; }
@@ -920,5 +927,87 @@ RT_DEV void trace_threaded_typed(DBG_DECL const View &S, uint32_t n_nodes, V3 o,
             if (better & anyhit) { cur = RT_END; sp_m = 0u; }
         }
     }
+}
+
+// ------------------------------------------------------------------ flat traversal of small scenes
+// f32 rounding is monotone, so with a FINITE reciprocal direction the slab interval of a box contains
+// the slab interval of every box inside it: a ray that hits a node's box has hit all its ancestors'
+// (tests/test_box_containment.py).  cast_ray_bvh's unpruned walk therefore tests exactly the leaves
+// whose OWN boxes are hit, and the tree above them only decides the order.  For scenes of at most 64
+// primitive records (all three scenes the reference ships) the walk is replaced by
+//   1. one wave-uniform loop over the leaf boxes — no cursor, no escape links, no per-lane node
+//      fetch: the box is the same for all lanes (an LDS broadcast read), every lane with a ray
+//      is busy in every trip, and min/max replace the compare-and-swap (no NaN can occur);
+//   2. a 64-bit mask of the records to test (OR of the hit leaves' masks), split by type, walked with
+//      ctz in three homogeneous loops as in trace_threaded_typed.
+// Order only matters for equal t: then the record that comes first in this octant's depth-first order
+// wins (flat_rank, built at upload), which is what the reference's strict `<` in visiting order does.
+// Rays with a zero / subnormal direction component (1/d infinite: 0 * inf = NaN makes a child box
+// "hit" where its parent "misses") and scenes whose boxes do not nest keep the tree walk.
+RT_DEV uint32_t flat_rank_of(const DevScene &sc, uint32_t octant, uint32_t rec)
+{
+    return (sc.flat_rank[octant * 16u + (rec >> 2)] >> (8u * (rec & 3u))) & 0xffu;
+}
+
+template <class View>
+RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V3 inv, bool anyhit, Hit &h)
+{
+    uint32_t all_lo = 0u, all_hi = 0u;
+#pragma unroll 1 // (unrolled by two the compiler spills ~900 registers)
+    for (uint32_t L = 0; L < sc.n_leaves; L++) {
+        DBG_WAVE_TICK(10);
+        DBG_ADD(11, 1);
+        const float4 n0 = S.flat(2u * L), n1 = S.flat(2u * L + 1u);
+        const float ax = (n0.x - o.x) * inv.x, bx = (n1.x - o.x) * inv.x;
+        const float ay = (n0.y - o.y) * inv.y, by = (n1.y - o.y) * inv.y;
+        const float az = (n0.z - o.z) * inv.z, bz = (n1.z - o.z) * inv.z;
+        const float t_0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz)), 0.0f);
+        const float t_1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz)), RT_INFINITY);
+        const bool miss = t_0 > t_1;
+        all_lo |= miss ? 0u : as_u(n0.w); // .w: the leaf's records as a 64-bit mask
+        all_hi |= miss ? 0u : as_u(n1.w);
+    }
+    const unsigned long long all_m = ((unsigned long long)all_hi << 32) | all_lo;
+    const unsigned long long tri_all = ((unsigned long long)sc.tri_mask_hi << 32) | sc.tri_mask_lo;
+    const unsigned long long pl_all = ((unsigned long long)sc.plane_mask_hi << 32) | sc.plane_mask_lo;
+    unsigned long long tri_m = all_m & tri_all, pl_m = all_m & pl_all, sp_m = all_m & ~(tri_all | pl_all);
+    const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+#define RT_FLAT_ACCEPT(t, rec)                                                                                         \
+    bool better = ((t) >= 0.0f) & ((t) < h.t);                                                                         \
+    if (((t) == h.t) & (h.t < RT_INFINITY)) better = flat_rank_of(sc, octant, (rec)) < flat_rank_of(sc, octant, h.ref); \
+    h.t = better ? (t) : h.t;                                                                                          \
+    h.ref = better ? (rec) : h.ref;
+    while (tri_m != 0ull) {
+        DBG_WAVE_TICK(12);
+        DBG_ADD(13, 1);
+        const uint32_t rec = (uint32_t)__builtin_ctzll(tri_m);
+        tri_m &= tri_m - 1ull;
+        const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u);
+        float u, v;
+        const float t = triangle_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), u, v);
+        RT_FLAT_ACCEPT(t, rec)
+        if (better & anyhit) tri_m = pl_m = sp_m = 0ull;
+    }
+    while (pl_m != 0ull) {
+        DBG_WAVE_TICK(15);
+        DBG_ADD(13, 1);
+        const uint32_t rec = (uint32_t)__builtin_ctzll(pl_m);
+        pl_m &= pl_m - 1ull;
+        const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u), r3 = S.prim(4u * rec + 3u);
+        const float t = plane_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), v3(r3.x, r3.y, r3.z));
+        RT_FLAT_ACCEPT(t, rec)
+        if (better & anyhit) pl_m = sp_m = 0ull;
+    }
+    while (sp_m != 0ull) {
+        DBG_WAVE_TICK(28);
+        DBG_ADD(13, 1);
+        const uint32_t rec = (uint32_t)__builtin_ctzll(sp_m);
+        sp_m &= sp_m - 1ull;
+        const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u);
+        const float t = sphere_t(o, d, v3(r0.x, r0.y, r0.z), r1.y);
+        RT_FLAT_ACCEPT(t, rec)
+        if (better & anyhit) sp_m = 0ull;
+    }
+#undef RT_FLAT_ACCEPT
 }
 

@@ -58,7 +58,9 @@ RT_DEV uint32_t stage_of_tag(uint32_t tag)
 #ifndef RT_POOL_WAVES_PER_SIMD
 #define RT_POOL_WAVES_PER_SIMD 5
 #endif
-template <bool LDS, uint32_t POOL, bool TYPED>
+// TRAV: which traversal TRACE runs — 0 trace_threaded (any BVH), 1 trace_threaded_typed (leaves of <= 8
+// primitives), 2 trace_flat (<= 64 primitive records, nested boxes; rays with a non-finite 1/d fall back to 0)
+template <bool LDS, uint32_t POOL, int TRAV>
 __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
 {
     typedef PoolLayout<POOL> L;
@@ -198,8 +200,21 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 h.src = SRC_BVH;
                 h.t = HOTF(H_T, slot); h.ref = 0; h.u = h.v = 0.0f; // ref of an earlier call stays in the cold column unless beaten
                 const float t_in = h.t;
-                if (TYPED) trace_threaded_typed(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
-                else trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
+                if (TRAV == 2) {
+                    const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+                    // 0 * x is NaN exactly when x is infinite or NaN (an overflowing sum only sends a ray the long way round)
+                    const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f;
+                    if (finite == 0.0f) {
+                        trace_flat(DBG_ARG S, sc, o, d, inv, shadow && anyhit_shadow, h);
+                        cur = RT_END;
+                    } else {
+                        trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, 0xffffffffu, cur, h);
+                    }
+                } else if (TRAV == 1) {
+                    trace_threaded_typed(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
+                } else {
+                    trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
+                }
                 const bool done = cur == RT_END;
                 SETH(H_T, slot, h.t);
                 if (!shadow && h.t < t_in) COLD(C_REF, slot) = h.ref; // this call found a closer hit

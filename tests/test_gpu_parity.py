@@ -78,19 +78,19 @@ def test_matches_oracle_live(name, w, h, spp, mb, big_env):
     assert (st["paths"], st["ext_rays"], st["shadow_rays"]) == (ost["paths"], ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("variant,typed", [("0", "1"), ("1", "1"), ("2", "1"), ("2", "0")])
-def test_every_kernel_variant_is_bit_exact(variant, typed, big_env, monkeypatch):
+@pytest.mark.parametrize("variant,traversal", [("0", "2"), ("1", "2"), ("2", "2"), ("2", "1"), ("2", "0")])
+def test_every_kernel_variant_is_bit_exact(variant, traversal, big_env, monkeypatch):
     """RSRT_KERNEL: 0 = lockstep megakernel, 1/2 = stage-scheduled wave-pool kernel (192/160 slots per wave);
-    RSRT_TYPED_LEAVES=0: the generic in-order leaf loop instead of the per-type loops.
+    RSRT_TRAVERSAL caps the traversal: 2 flat small-scene loop, 1 tree walk with per-type leaf loops, 0 generic tree walk.
     Scheduling differs, the per-path arithmetic does not: all must give the oracle's bits."""
     monkeypatch.setenv("RSRT_KERNEL", variant)
-    monkeypatch.setenv("RSRT_TYPED_LEAVES", typed)
+    monkeypatch.setenv("RSRT_TRAVERSAL", traversal)
     for name, w, h, spp, mb in [("house", 150, 70, 6, 8), ("suzanne", 64, 48, 3, 10)]:
         sc = R.Scene.load_toml(util.scene_path(name))
         ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), w, h, 0, spp, mb)
         for flags in (0, R.state.FLAG_REFERENCE_TRAVERSAL):
             img, st = gpu_render(sc, big_env, w, h, 0, spp, mb, flags)
-            assert np.array_equal(util.bits(img), util.bits(ref)), (name, variant, typed, flags)
+            assert np.array_equal(util.bits(img), util.bits(ref)), (name, variant, traversal, flags)
             assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
@@ -365,3 +365,34 @@ def test_short_reciprocal_is_the_ieee_quotient_for_every_input(big_env):
     assert r["mismatches"] == 0, hex(r["first_bad"])
     assert r["short_path_inputs"] == 2 * 251 * 2 ** 23
     assert r["bare_rcp_wrong"] > 0  # the comparison is live: the bare instruction is NOT correctly rounded
+
+
+def test_foreign_bvh_with_long_leaves_uses_the_generic_loop(big_env):
+    """A host may upload any valid BVH.  Two leaves of ~11 primitives each (more than the 8 the per-type leaf
+    masks hold) must take the generic in-order leaf loop and still give the oracle's bits."""
+    base = R.Scene.load_toml(util.scene_path("default"))
+    nodes, prims = base.bvh_nodes, base.primitives
+    leaves = [n for n in nodes if n["primitives_len"] > 0]
+    leaves.sort(key=lambda n: int(n["primitives_or_second_child_index"]))
+    half = len(prims) // 2
+    cut = min((int(n["primitives_or_second_child_index"]) for n in leaves), key=lambda i: abs(i - half))
+    assert 8 < cut < len(prims) - 8
+
+    def union(sel):
+        return (np.min([n["bounds_min"] for n in sel], axis=0), np.max([n["bounds_max"] for n in sel], axis=0))
+
+    new = np.zeros(3, nodes.dtype)
+    new[0]["bounds_min"], new[0]["bounds_max"] = union(leaves)
+    new[0]["primitives_or_second_child_index"], new[0]["primitives_len"], new[0]["split_axis"] = 2, 0, 0
+    a = [n for n in leaves if int(n["primitives_or_second_child_index"]) < cut]
+    b = [n for n in leaves if int(n["primitives_or_second_child_index"]) >= cut]
+    new[1]["bounds_min"], new[1]["bounds_max"] = union(a)
+    new[1]["primitives_or_second_child_index"], new[1]["primitives_len"] = 0, cut
+    new[2]["bounds_min"], new[2]["bounds_max"] = union(b)
+    new[2]["primitives_or_second_child_index"], new[2]["primitives_len"] = cut, len(prims) - cut
+    sc = R.Scene(base.materials, base.spheres, base.plane_descs, base.vertices, base.normals, base.triangles, base.camera_desc,
+                 planes=base.planes, primitives=prims, bvh_nodes=new, bvh_depth=2)
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 96, 64, 0, 4, 10)
+    img, st = gpu_render(sc, big_env, 96, 64, 0, 4, 10)
+    assert np.array_equal(util.bits(img), util.bits(ref))
+    assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
