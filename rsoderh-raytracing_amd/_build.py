@@ -79,7 +79,7 @@ def build_hip(force=False, extra_flags=(), instrument=False):
         if force or _newer(target, _deps("hip")):
             tmp = target + ".tmp%d" % os.getpid()
             _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                  "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", INCLUDE, "-o", tmp] + flags + srcs)
+                  "-fno-fast-math", "-fno-slp-vectorize", "-fno-vectorize", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", INCLUDE, "-o", tmp] + flags + srcs)
             os.replace(tmp, target)
     return target
 

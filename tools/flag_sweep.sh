@@ -5,7 +5,7 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 SRC="$ROOT/rsoderh-raytracing_amd/csrc/hip/rsrt_api.hip"
-BASE="--offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -I $ROOT/include"
+BASE="--offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fno-vectorize -I $ROOT/include"
 mkdir -p "$ROOT/build_exp"
 if [ "$1" = build ]; then
   i=0
