@@ -730,7 +730,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     const size_t esc_f4 = (8ull * n_nodes + 3) / 4;
     // ---- flat small-scene traversal (rt_device.h, trace_flat): leaf list, record masks, per-octant visiting ranks
     std::vector<uint32_t> leaf_nodes;
-    bool flat_ok = n_primitives <= 64;
+    bool flat_ok = n_primitives <= 64; // ... and few enough leaves that testing every leaf box beats the tree walk (checked below)
     for (uint32_t i = 0; i < n_nodes; i++) {
         const rsrt_bvh_node &nd = nodes[i];
         if (nd.primitives_len != 0) { leaf_nodes.push_back(i); continue; }
@@ -738,6 +738,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
             for (int k = 0; k < 3; k++)
                 flat_ok = flat_ok && nodes[c].bounds_min[k] >= nd.bounds_min[k] && nodes[c].bounds_max[k] <= nd.bounds_max[k];
     }
+    flat_ok = flat_ok && leaf_nodes.size() <= 32;
     std::vector<uint32_t> flat_rank(8 * 16, 0u);
     uint64_t tri_mask = 0, plane_mask = 0;
     if (flat_ok) {

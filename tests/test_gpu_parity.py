@@ -396,3 +396,24 @@ def test_foreign_bvh_with_long_leaves_uses_the_generic_loop(big_env):
     img, st = gpu_render(sc, big_env, 96, 64, 0, 4, 10)
     assert np.array_equal(util.bits(img), util.bits(ref))
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+
+
+def test_bvh_whose_boxes_do_not_nest_keeps_the_tree_walk(big_env):
+    """The flat small-scene loop is only valid when every child box lies inside its parent's.  Shrink an interior
+    node's box so that its children stick out: the reference (and the oracle) then skip that subtree for rays that
+    miss the shrunken box although they would hit a child — and so must the product."""
+    base = R.Scene.load_toml(util.scene_path("default"))
+    nodes = base.bvh_nodes.copy()
+    interior = [i for i in range(1, len(nodes)) if nodes[i]["primitives_len"] == 0]
+    i = interior[0]
+    mid = (nodes[i]["bounds_min"] + nodes[i]["bounds_max"]) * np.float32(0.5)
+    nodes[i]["bounds_min"] = mid + (nodes[i]["bounds_min"] - mid) * np.float32(0.5)
+    nodes[i]["bounds_max"] = mid + (nodes[i]["bounds_max"] - mid) * np.float32(0.5)
+    sc = R.Scene(base.materials, base.spheres, base.plane_descs, base.vertices, base.normals, base.triangles, base.camera_desc,
+                 planes=base.planes, primitives=base.primitives, bvh_nodes=nodes, bvh_depth=base.bvh_depth)
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 96, 64, 0, 4, 10)
+    intact, _ = oracle.render(util.oracle_scene(base), util.oracle_env(big_env), base.camera_uniform().view(oracle.CAMERA), 96, 64, 0, 4, 10)
+    assert not np.array_equal(util.bits(ref), util.bits(intact))  # the shrunken box does change the picture
+    img, st = gpu_render(sc, big_env, 96, 64, 0, 4, 10)
+    assert np.array_equal(util.bits(img), util.bits(ref))
+    assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
