@@ -953,10 +953,7 @@ template <class View>
 RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V3 inv, bool anyhit, Hit &h)
 {
     uint32_t all_lo = 0u, all_hi = 0u;
-#ifndef RT_FLAT_UNROLL
-#define RT_FLAT_UNROLL 1
-#endif
-#pragma unroll RT_FLAT_UNROLL
+#pragma unroll 1 // (unrolling by 2 or 4 measures the same)
     for (uint32_t L = 0; L < sc.n_leaves; L++) {
         DBG_WAVE_TICK(10);
         DBG_ADD(11, 1);
