@@ -417,3 +417,46 @@ def test_bvh_whose_boxes_do_not_nest_keeps_the_tree_walk(big_env):
     img, st = gpu_render(sc, big_env, 96, 64, 0, 4, 10)
     assert np.array_equal(util.bits(img), util.bits(ref))
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+
+
+@pytest.mark.parametrize("traversal", ["2", "1", "0"])
+def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_env, monkeypatch):
+    """Every primitive exists three times, at the same place, with three different materials, so every hit is a
+    tie of equal t between records that usually sit in different leaves.  The reference keeps the first one it
+    visits (strict `<`, near-child-first order, which depends on the ray's sign octant); the material of the
+    winner is visible in the picture.  Exercises the visiting-order ranks of the flat traversal and the position
+    rule of the typed leaf loops."""
+    from rsoderh_raytracing_amd import host, types as T
+    monkeypatch.setenv("RSRT_TRAVERSAL", traversal)
+    rng = np.random.default_rng(23)
+    mats = np.zeros(3, T.MATERIAL)
+    mats["color"] = [[0.9, 0.1, 0.1], [0.1, 0.9, 0.1], [0.1, 0.1, 0.9]]
+    mats["roughness"] = [1.0, 0.4, 0.8]
+    mats["metallic"] = [0.0, 0.5, 0.0]
+    mats["emission"] = [[0.3, 0, 0], [0, 0.3, 0], [0, 0, 0.3]]
+    ns, npl, nt = 2, 1, 6
+    sph = np.zeros(3 * ns, T.SPHERE)
+    pos, rad = rng.uniform(-2, 2, (ns, 3)), rng.uniform(0.4, 0.9, ns)
+    pls = np.zeros(3 * npl, T.PLANE_DESC)
+    ppos, pf, pr = np.array([[-4.0, -1.5, -4.0]]), np.array([[0.0, 0.0, 8.0]]), np.array([[8.0, 0.0, 0.0]])
+    tv = np.round(rng.uniform(-3, 3, (nt, 3, 3)) * 2) / 2
+    verts = np.zeros(9 * nt, T.VEC3)
+    norms = np.zeros(9 * nt, T.VEC3)
+    tri = np.zeros(3 * nt, T.TRIANGLE)
+    order = rng.permutation(3 * nt)  # copies scattered through the arrays
+    for copy in range(3):
+        sph["pos"][copy::3], sph["radius"][copy::3], sph["material_id"][copy::3] = pos, rad, (copy + 1) % 3
+        pls["pos"][copy::3], pls["forward"][copy::3], pls["right"][copy::3], pls["material_id"][copy::3] = ppos, pf, pr, (copy + 2) % 3
+        for k in range(nt):
+            j = int(order[copy * nt + k])
+            verts["v"][3 * j:3 * j + 3] = tv[k]
+            n = np.cross(tv[k][1] - tv[k][0], tv[k][2] - tv[k][0])
+            norms["v"][3 * j:3 * j + 3] = n / max(np.linalg.norm(n), 1e-6)
+            tri[j] = (3 * j, 3 * j + 1, 3 * j + 2, 3 * j, 3 * j + 1, 3 * j + 2, copy)
+    cam = host.make_camera_desc([0.3, 1.0, 6.0], yaw=0.05, pitch=-0.1, fov_y=1.2)
+    sc = R.Scene(mats, sph, pls, verts, norms, tri, cam)
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 96, 64, 0, 6, 6)
+    img, st = gpu_render(sc, big_env, 96, 64, 0, 6, 6)
+    same = util.bits(img) == util.bits(ref)
+    assert same.all(), (traversal, int((~same).any(axis=2).sum()))
+    assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])

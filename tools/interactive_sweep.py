@@ -5,8 +5,8 @@ import util
 import rsoderh_raytracing_amd as R
 env = R.Environment.synthetic(2048, 1024)
 sc = R.Scene.load_toml(util.scene_path('house'))
-for b in ('1', '2', '3', '4'):
-    os.environ['RSRT_BLOCKS_PER_CU'] = b
+for kv, b in [('2', '5'), ('2', '4'), ('2', '3'), ('2', '2'), ('1', '4'), ('1', '2'), ('0', '8')]:
+    os.environ['RSRT_BLOCKS_PER_CU'] = b; os.environ['RSRT_KERNEL'] = kv
     st = R.State.new(sc, env, 1920, 1080); st.max_bounces = 10
     for spp in (1, 4):
         st.render_range(0, spp); st.synchronize(); st.stats()
@@ -14,5 +14,5 @@ for b in ('1', '2', '3', '4'):
         for i in range(50): st.render_range(0, spp)
         st.synchronize(); dt = (time.perf_counter() - t) / 50
         g = st.stats()
-        print(f'blocks/CU {b} spp/call {spp}: wall {dt*1e3:.2f} ms  kernel {g["kernel_ms"]/50:.2f} ms (trace {g["trace_kernel_ms"]/50:.2f}, resolve {g["resolve_kernel_ms"]/50:.3f})', flush=True)
+        print(f'kernel {kv} blocks/CU {b} spp/call {spp}: wall {dt*1e3:.2f} ms  kernel {g["kernel_ms"]/50:.2f} ms (trace {g["trace_kernel_ms"]/50:.2f}, resolve {g["resolve_kernel_ms"]/50:.3f})', flush=True)
     st.close()
