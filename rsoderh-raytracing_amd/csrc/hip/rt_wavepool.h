@@ -217,10 +217,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 }
                 const bool done = cur == RT_END;
                 SETH(H_T, slot, h.t);
-                if (!shadow && h.t < t_in) COLD(C_REF, slot) = h.ref; // this call found a closer hit
+                if (TRAV != 2 && !shadow && h.t < t_in) COLD(C_REF, slot) = h.ref; // this call found a closer hit
                 if (done) {
                     if (shadow) { n_shadow++; SET_TAG(slot, TAG_BSDF); } // H_T < INFINITY <=> occluded
-                    else { n_ext++; SET_TAG(slot, h.did_hit() ? TAG_SHADE : TAG_MISS); }
+                    else if (TRAV == 2) { n_ext++; SET_CUR_TAG(slot, h.ref, h.did_hit() ? TAG_SHADE : TAG_MISS); } // flat: every ray finishes here and records
+                    else { n_ext++; SET_TAG(slot, h.did_hit() ? TAG_SHADE : TAG_MISS); }                            // fit the idle cursor bits: no cold column
                 } else {
                     SET_CUR_TAG(slot, cur, ct & 7u);
                 }
@@ -244,8 +245,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 }
                 if (h.did_hit()) {
                     SETH(H_T, slot, h.t);
-                    COLD(C_REF, slot) = h.ref | (h.src << 30);
-                    SET_TAG(slot, TAG_SHADE);
+                    if (TRAV == 2) {
+                        SET_CUR_TAG(slot, h.ref | (h.src << 6), TAG_SHADE);
+                    } else {
+                        COLD(C_REF, slot) = h.ref | (h.src << 30);
+                        SET_TAG(slot, TAG_SHADE);
+                    }
                 } else { // escaped: shader.wgsl:1222-1231
                     float u, v;
                     direction_to_equirectangular_uv(d, u, v);
@@ -267,8 +272,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 const V3 d = v3(HOTF(H_DX, slot), HOTF(H_DY, slot), HOTF(H_DZ, slot));
                 Hit h;
                 h.t = HOTF(H_T, slot);
-                const uint32_t hr = COLD(C_REF, slot);
-                h.ref = hr & 0x3fffffffu; h.src = hr >> 30;
+                if (TRAV == 2) {
+                    const uint32_t hr = HOT(H_CT, slot) >> 3;
+                    h.ref = hr & 63u; h.src = hr >> 6;
+                } else {
+                    const uint32_t hr = COLD(C_REF, slot);
+                    h.ref = hr & 0x3fffffffu; h.src = hr >> 30;
+                }
                 hit_barycentrics(S, h, o, d); // not carried through the traversal: the same test gives the same bits
                 uint32_t rng = COLD(C_RNG, slot);
                 const V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
