@@ -660,7 +660,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
     DeviceGuard g(ctx->device);
     if (n_nodes == 0 || !nodes) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh_nodes is empty");
-    if (n_nodes >= RT_END) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh_nodes: %u nodes exceed the 29-bit traversal cursor", n_nodes);
+    if (n_nodes >= RT_END) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh_nodes: %u nodes exceed the 25-bit traversal cursor", n_nodes);
     if ((n_materials && !materials) || (n_spheres && !spheres) || (n_planes && !planes) || (n_vertices && !vertices) ||
         (n_normals && !normals) || (n_triangles && !triangles) || (n_primitives && !primitives))
         return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "a non-empty array has a NULL pointer");

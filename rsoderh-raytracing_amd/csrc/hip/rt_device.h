@@ -736,7 +736,7 @@ RT_DEV bool slab_test(float4 n0, float4 n1, V3 o, V3 inv, float &t_entry)
 // Same boxes, same primitives, same order, same strict-< replacement as cast_ray_bvh — but the only
 // traversal state is `cur`, so a traversal can stop after `budget` steps and be resumed later by
 // any lane (h carries the best hit so far).
-#define RT_END 0x1fffffffu // 29 bits: the pool kernel keeps cursor and stage tag in one word
+#define RT_END 0x1ffffffu // 25 bits: the pool kernel keeps cursor, flags and stage tag in one word
 #ifndef RT_LEAFQ
 #define RT_LEAFQ 4
 #endif

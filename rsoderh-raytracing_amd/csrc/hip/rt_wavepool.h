@@ -12,33 +12,46 @@
 // only which lane executes which step, and when, changes.  No workgroup barrier is used after the
 // scene is staged: waves are independent.
 //
-// Where the state lives (measured: run time scales ~linearly with resident waves, and LDS is what
-// limits them): the HOT columns — what the traversal loop touches: ray, traversal cursor, best hit,
-// tag — are in LDS, 9 dwords per slot; the COLD columns — throughput, radiance, RNG, NEE carry,
-// shading normal, the best hit's record / barycentrics ... only read/written by the shading stages
-// (and once per improved hit) — are in a global-memory arena (25 dwords per slot, one contiguous
-// column per field and wave, so a stage's accesses coalesce).  POOL = 192 then costs 7.2 KB of LDS
-// per wave: 16 waves per CU, with 3 slots per lane to pick a full stage from.
+// Where the state lives (measured: run time scales ~linearly with resident waves up to 3 per SIMD, and LDS
+// is what limits them): the HOT columns — what a TRACE invocation needs: the vertex the rays start from,
+// the extension direction, the shadow direction, best t, and one word of tag / flags / traversal cursor —
+// are in LDS, 11 dwords per slot; the COLD columns — throughput, radiance, the pending NEE term, RNG ... —
+// only read / written by the shading stages, are in a global-memory arena (14 dwords per slot, one
+// contiguous column per field and wave, so a stage's accesses coalesce).
 //
-// Stages: GEN (take the next (pixel, sample) of the wave's chunk, build the camera ray)
-//         TRACE (extension rays: closest hit; NEE shadow rays: any hit — one shared, resumable loop)
-//         MISS (cast_ray's brute-force fallback, then the escape to the environment)
-//         SHADE (resolve the hit, emission, sample the environment for NEE)
-//         BSDF (NEE contribution, BSDF sample, throughput, termination)
+// Stages: GEN    take the next (pixel, sample) of the wave's chunk, build the camera ray
+//         TRACE  one ray of the slot: its NEE shadow ray first (any hit), then its extension ray (closest hit)
+//         MISS   the extension ray missed the BVH: cast_ray's brute-force fallback, then the escape
+//         SHADE  everything the shader does at a hit (shader.wgsl:1233-1299): emission, environment sample,
+//                the NEE term, BSDF sample, throughput, termination — and first of all the NEE term of the
+//                PREVIOUS vertex, now that its shadow ray has been traced
+//         FINISH a path that ended at its last vertex but still had a shadow ray out: add the NEE term, store
+// "Deferred NEE": the shader adds a vertex's NEE term right after its shadow ray and before sampling the
+// BSDF.  Here SHADE computes the term and the BSDF sample in one go, parks the term (3 cold dwords),
+// and both rays of the vertex are traced from hot state alone; the term is added — or dropped, if
+// occluded — when the path is next touched (SHADE, MISS or FINISH), i.e. before anything else is added to
+// the radiance, so every sum is formed in the shader's order.  One shading stage per bounce instead of
+// two: a third fewer stage switches, and the state crosses the memory system once per bounce.
 #pragma once
 #include "rt_device.h"
 
-enum HotField { H_OX, H_OY, H_OZ, H_DX, H_DY, H_DZ, H_T, H_CT, H_COUNT }; // H_CT: traversal cursor << 3 | stage tag
+enum HotField { H_OX, H_OY, H_OZ, H_EX, H_EY, H_EZ, H_SX, H_SY, H_SZ, H_T, H_CT, H_COUNT };
+// H_CT: stage tag (3 bits) | flags (4 bits) | cursor of the traversal in progress, or the record of the hit it found (25 bits)
+enum CtBits : uint32_t {
+    F_SHADOW = 8u,    // a shadow ray (direction S) is still to be traced
+    F_EXT = 16u,      // an extension ray (direction E) is still to be traced
+    F_NEE = 32u,      // C_NEE* holds a term that is added unless F_OCCLUDED
+    F_OCCLUDED = 64u, // result of the shadow ray
+    CT_FLAGS = 120u,
+    CT_SHIFT = 7u
+};
 enum ColdField {
-    C_TX, C_TY, C_TZ, C_LX, C_LY, C_LZ, C_LASTPDF, C_RNG, C_BOUNCE, C_OUT,
-    C_WX, C_WY, C_WZ,             // direction the path arrived with at the current hit (wo = -w)
-    C_NX, C_NY, C_NZ, C_MAT,      // shading normal and material of the current hit
-    C_ERX, C_ERY, C_ERZ, C_EPDF, C_COS, // NEE sample: radiance, pdf, cos (0 = no contribution)
-    C_REF,                        // best hit of the extension ray: record | source << 30 (rewritten only when a TRACE call improves it)
+    C_TX, C_TY, C_TZ, C_LX, C_LY, C_LZ, C_NEEX, C_NEEY, C_NEEZ, C_LASTPDF, C_RNG, C_BOUNCE, C_OUT,
+    C_REF, // tree-walk traversals only: best hit of the extension ray, record | source << 30 (the flat traversal keeps it in H_CT)
     C_COUNT
 };
-enum PoolTag { TAG_FREE = 0, TAG_TRACE_EXT = 1, TAG_TRACE_SHADOW = 2, TAG_MISS = 3, TAG_SHADE = 4, TAG_BSDF = 5, TAG_IDLE = 6 };
-enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_BSDF = 4, ST_COUNT = 5 };
+enum PoolTag { TAG_FREE = 0, TAG_TRACE = 1, TAG_MISS = 2, TAG_SHADE = 3, TAG_FINISH = 4, TAG_IDLE = 5 };
+enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_FINISH = 4, ST_COUNT = 5 };
 
 template <uint32_t POOL>
 struct PoolLayout {
@@ -49,14 +62,10 @@ struct PoolLayout {
     static constexpr uint32_t kWaveColdDwords = C_COUNT * POOL;
 };
 
-RT_DEV uint32_t stage_of_tag(uint32_t tag)
-{
-    // FREE->GEN, TRACE_EXT/TRACE_SHADOW->TRACE, MISS, SHADE, BSDF; IDLE -> none
-    return tag == TAG_FREE ? ST_GEN : (tag <= TAG_TRACE_SHADOW ? ST_TRACE : (tag == TAG_IDLE ? ST_COUNT : tag - 1u));
-}
+RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE, MISS, SHADE, FINISH; IDLE -> ST_COUNT (none)
 
 #ifndef RT_POOL_WAVES_PER_SIMD
-#define RT_POOL_WAVES_PER_SIMD 5
+#define RT_POOL_WAVES_PER_SIMD 4
 #endif
 // TRAV: which traversal TRACE runs — 0 trace_threaded (any BVH), 1 trace_threaded_typed (leaves of <= 8
 // primitives), 2 trace_flat (<= 64 primitive records, nested boxes; rays with a non-finite 1/d fall back to 0)
@@ -81,8 +90,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
 #define HOTF(f, slot) as_f(W[(f) * POOL + (slot)])
 #define SETH(f, slot, val) W[(f) * POOL + (slot)] = as_u(val)
 #define TAG_OF(slot) (W[H_CT * POOL + (slot)] & 7u)
-#define SET_TAG(slot, tag) W[H_CT * POOL + (slot)] = (uint32_t)(tag)              /* cursor := root (0) */
-#define SET_CUR_TAG(slot, cur, tag) W[H_CT * POOL + (slot)] = ((cur) << 3) | (uint32_t)(tag)
+#define SET_TAG(slot, tag) W[H_CT * POOL + (slot)] = (uint32_t)(tag)              /* no flags, cursor := root (0) */
+#define SET_CT(slot, payload, flags, tag) W[H_CT * POOL + (slot)] = ((payload) << CT_SHIFT) | (flags) | (uint32_t)(tag)
 #define COLD(f, slot) G[(f) * POOL + (slot)]
 #define COLDF(f, slot) as_f(G[(f) * POOL + (slot)])
 #define SETC(f, slot, val) G[(f) * POOL + (slot)] = as_u(val)
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                         PathState ps;
                         start_path(P, px, py, P.sample_begin + srel, ps);
                         SETH(H_OX, slot, ps.o.x); SETH(H_OY, slot, ps.o.y); SETH(H_OZ, slot, ps.o.z);
-                        SETH(H_DX, slot, ps.d.x); SETH(H_DY, slot, ps.d.y); SETH(H_DZ, slot, ps.d.z);
+                        SETH(H_EX, slot, ps.d.x); SETH(H_EY, slot, ps.d.y); SETH(H_EZ, slot, ps.d.z);
                         SETH(H_T, slot, RT_INFINITY);
                         SETC(C_TX, slot, 1.0f); SETC(C_TY, slot, 1.0f); SETC(C_TZ, slot, 1.0f);
                         SETC(C_LX, slot, 0.0f); SETC(C_LY, slot, 0.0f); SETC(C_LZ, slot, 0.0f);
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                         COLD(C_RNG, slot) = ps.rng;
                         COLD(C_BOUNCE, slot) = 0u;
                         COLD(C_OUT, slot) = srel * P.n_slots + chunk_tile_slot0 + p;
-                        SET_TAG(slot, TAG_TRACE_EXT);
+                        SET_CT(slot, 0u, F_EXT, TAG_TRACE);
                         n_paths++;
                     }
                     // an out-of-frame pixel of an edge tile: the slot stays FREE and is offered again
@@ -187,16 +196,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                     if (lane + 64u * k < POOL && TAG_OF(lane + 64u * k) == TAG_FREE) SET_TAG(lane + 64u * k, TAG_IDLE);
             }
         } else if (best == ST_TRACE) {
-            // ---------------- TRACE: cast_ray_bvh for extension and shadow rays together.  The slot's
-            // o / d ARE the ray to trace (SHADE already moved a shadow ray's origin to the hit point).
+            // ---------------- TRACE: one ray of the slot from its vertex O — the shadow ray (direction S, any
+            // hit) while one is pending, else the extension ray (direction E, closest hit): cast_ray_bvh
             if (on) {
                 const uint32_t ct = HOT(H_CT, slot);
-                const bool shadow = (ct & 7u) == TAG_TRACE_SHADOW;
+                const bool shadow = (ct & F_SHADOW) != 0u;
+                const uint32_t dcol = shadow ? (uint32_t)H_SX : (uint32_t)H_EX;
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
-                const V3 d = v3(HOTF(H_DX, slot), HOTF(H_DY, slot), HOTF(H_DZ, slot));
-                // resume (or start: cur = root, best = INFINITY) the threaded traversal for a bounded number of steps
+                const V3 d = v3(HOTF(dcol, slot), HOTF(dcol + 1u, slot), HOTF(dcol + 2u, slot));
+                // resume (or start: cur = root, best = INFINITY) the traversal
                 Hit h;
-                uint32_t cur = ct >> 3;
+                uint32_t cur = ct >> CT_SHIFT;
                 h.src = SRC_BVH;
                 h.t = HOTF(H_T, slot); h.ref = 0; h.u = h.v = 0.0f; // ref of an earlier call stays in the cold column unless beaten
                 const float t_in = h.t;
@@ -216,21 +226,29 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                     trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
                 }
                 const bool done = cur == RT_END;
-                SETH(H_T, slot, h.t);
-                if (TRAV != 2 && !shadow && h.t < t_in) COLD(C_REF, slot) = h.ref; // this call found a closer hit
-                if (done) {
-                    if (shadow) { n_shadow++; SET_TAG(slot, TAG_BSDF); } // H_T < INFINITY <=> occluded
-                    else if (TRAV == 2) { n_ext++; SET_CUR_TAG(slot, h.ref, h.did_hit() ? TAG_SHADE : TAG_MISS); } // flat: every ray finishes here and records
-                    else { n_ext++; SET_TAG(slot, h.did_hit() ? TAG_SHADE : TAG_MISS); }                            // fit the idle cursor bits: no cold column
+                if (!done) { // to be resumed: best t and cursor
+                    SETH(H_T, slot, h.t);
+                    if (TRAV != 2 && !shadow && h.t < t_in) COLD(C_REF, slot) = h.ref;
+                    SET_CT(slot, cur, ct & CT_FLAGS, TAG_TRACE);
+                } else if (shadow) {
+                    n_shadow++;
+                    SETH(H_T, slot, RT_INFINITY); // the extension ray starts fresh
+                    const uint32_t fl = (ct & (F_EXT | F_NEE)) | (h.t < RT_INFINITY ? (uint32_t)F_OCCLUDED : 0u);
+                    SET_CT(slot, 0u, fl, (ct & F_EXT) ? TAG_TRACE : TAG_FINISH);
                 } else {
-                    SET_CUR_TAG(slot, cur, ct & 7u);
+                    n_ext++;
+                    SETH(H_T, slot, h.t);
+                    if (TRAV != 2 && h.t < t_in) COLD(C_REF, slot) = h.ref; // this call found a closer hit
+                    // the flat traversal's records fit the idle cursor bits: no cold column
+                    SET_CT(slot, TRAV == 2 ? h.ref : 0u, ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
                 }
             }
         } else if (best == ST_MISS) {
             // ---------------- MISS: brute-force fallback of cast_ray (shader.wgsl:583-598), then escape
             if (on) {
+                const uint32_t ct = HOT(H_CT, slot);
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
-                const V3 d = v3(HOTF(H_DX, slot), HOTF(H_DY, slot), HOTF(H_DZ, slot));
+                const V3 d = v3(HOTF(H_EX, slot), HOTF(H_EY, slot), HOTF(H_EZ, slot));
                 Hit h;
                 h.t = RT_INFINITY; h.ref = 0; h.src = SRC_BVH; h.u = h.v = 0.0f;
                 for (uint32_t i = 0; i < sc.n_spheres; i++) {
@@ -243,13 +261,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                     float t = test_record(S, i, SRC_FB_PLANE, o, d, u, v);
                     if (t >= 0.0f && t < h.t) { h.t = t; h.ref = i; h.src = SRC_FB_PLANE; }
                 }
-                if (h.did_hit()) {
+                if (h.did_hit()) { // SHADE takes it from here (and settles the pending NEE term)
                     SETH(H_T, slot, h.t);
                     if (TRAV == 2) {
-                        SET_CUR_TAG(slot, h.ref | (h.src << 6), TAG_SHADE);
+                        SET_CT(slot, h.ref | (h.src << 6), ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
                     } else {
                         COLD(C_REF, slot) = h.ref | (h.src << 30);
-                        SET_TAG(slot, TAG_SHADE);
+                        SET_CT(slot, 0u, ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
                     }
                 } else { // escaped: shader.wgsl:1222-1231
                     float u, v;
@@ -259,6 +277,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                     const float w = power_heuristic(COLDF(C_LASTPDF, slot), pdf);
                     const V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
                     V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
+                    if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot)); // previous vertex, lit
                     Lr = Lr + T * sky * w;
                     float *dst = P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u;
                     dst[0] = Lr.x; dst[1] = Lr.y; dst[2] = Lr.z;
@@ -266,14 +285,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 }
             }
         } else if (best == ST_SHADE) {
-            // ---------------- SHADE: hit attributes, emission, environment sample (shader.wgsl:1233-1247)
+            // ---------------- SHADE: one whole iteration of trace_ray's loop body at a hit (shader.wgsl:1233-1299)
             if (on) {
+                const uint32_t ct = HOT(H_CT, slot);
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
-                const V3 d = v3(HOTF(H_DX, slot), HOTF(H_DY, slot), HOTF(H_DZ, slot));
+                const V3 d = v3(HOTF(H_EX, slot), HOTF(H_EY, slot), HOTF(H_EZ, slot));
                 Hit h;
                 h.t = HOTF(H_T, slot);
                 if (TRAV == 2) {
-                    const uint32_t hr = HOT(H_CT, slot) >> 3;
+                    const uint32_t hr = ct >> CT_SHIFT;
                     h.ref = hr & 63u; h.src = hr >> 6;
                 } else {
                     const uint32_t hr = COLD(C_REF, slot);
@@ -281,84 +301,71 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 }
                 hit_barycentrics(S, h, o, d); // not carried through the traversal: the same test gives the same bits
                 uint32_t rng = COLD(C_RNG, slot);
-                const V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
+                V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
                 V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
+                const uint32_t bounce = COLD(C_BOUNCE, slot) + 1u;
+                // the previous vertex's NEE term, lit: :1246-1249 of the previous iteration
+                if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot));
                 const Surface surf = resolve_hit(S, h, o, d);
                 const BsdfMaterial mat = load_material(S, surf.material_id);
                 Lr = Lr + T * mat.emission;
                 const EnvironmentSample es = sample_environment(P.env, rng);
                 const float cos_nee = fmax_(0.0f, dot(surf.normal, es.direction));
-                const bool want_shadow = cos_nee > 0.0f && es.pdf > 0.0f;
-                SETC(C_LX, slot, Lr.x); SETC(C_LY, slot, Lr.y); SETC(C_LZ, slot, Lr.z);
-                COLD(C_RNG, slot) = rng;
-                SETC(C_WX, slot, d.x); SETC(C_WY, slot, d.y); SETC(C_WZ, slot, d.z);
-                SETC(C_NX, slot, surf.normal.x); SETC(C_NY, slot, surf.normal.y); SETC(C_NZ, slot, surf.normal.z);
-                COLD(C_MAT, slot) = surf.material_id;
-                SETC(C_ERX, slot, es.radiance.x); SETC(C_ERY, slot, es.radiance.y); SETC(C_ERZ, slot, es.radiance.z);
-                SETC(C_EPDF, slot, es.pdf);
-                SETC(C_COS, slot, want_shadow ? cos_nee : 0.0f);
-                // the next ray — the shadow ray now, the bounce later — starts at the hit point
-                SETH(H_OX, slot, surf.point.x); SETH(H_OY, slot, surf.point.y); SETH(H_OZ, slot, surf.point.z);
-                SETH(H_DX, slot, es.direction.x); SETH(H_DY, slot, es.direction.y); SETH(H_DZ, slot, es.direction.z);
-                SETH(H_T, slot, RT_INFINITY); // BSDF reads "H_T < INFINITY" as "occluded"
-                SET_TAG(slot, want_shadow ? TAG_TRACE_SHADOW : TAG_BSDF);
-            }
-        } else {
-            // ---------------- BSDF: NEE contribution, BSDF sample, throughput (shader.wgsl:1251-1299)
-            if (on) {
-                const V3 point = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
-                const V3 edir = v3(HOTF(H_DX, slot), HOTF(H_DY, slot), HOTF(H_DZ, slot));
-                const bool occluded = HOTF(H_T, slot) < RT_INFINITY;
-                const V3 d = v3(COLDF(C_WX, slot), COLDF(C_WY, slot), COLDF(C_WZ, slot));
-                const V3 normal = v3(COLDF(C_NX, slot), COLDF(C_NY, slot), COLDF(C_NZ, slot));
-                const uint32_t mat_id = COLD(C_MAT, slot);
-                V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
-                V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
-                const float cos_nee = COLDF(C_COS, slot);
-                const V3 erad = v3(COLDF(C_ERX, slot), COLDF(C_ERY, slot), COLDF(C_ERZ, slot));
-                const float epdf = COLDF(C_EPDF, slot);
-                uint32_t rng = COLD(C_RNG, slot);
-                const uint32_t bounce = COLD(C_BOUNCE, slot) + 1u;
-                const uint32_t out = COLD(C_OUT, slot);
-                const BsdfMaterial mat = load_material(S, mat_id);
-                const Frame frame = make_frame(normal); // shader.wgsl:1252 and :1133 build the same frame
+                const bool want_shadow = cos_nee > 0.0f && es.pdf > 0.0f; // a shadow ray is cast: :1246
+                const Frame frame = make_frame(surf.normal); // shader.wgsl:1252 and :1133 build the same frame
                 const V3 wo = to_frame_local(frame, -d);
-                if (cos_nee > 0.0f && !occluded) { // lit: cos > 0, pdf > 0, not occluded
-                    const V3 wi = to_frame_local(frame, edir);
+                V3 nee = v3(0.0f, 0.0f, 0.0f);
+                if (want_shadow) { // what :1247-1249 adds if the shadow ray comes back unoccluded
+                    const V3 wi = to_frame_local(frame, es.direction);
                     V3 scattering;
                     float pdf_bsdf;
                     bsdf_eval_pdf_local(wo, wi, mat, scattering, pdf_bsdf);
-                    const float w = power_heuristic(epdf, pdf_bsdf);
-                    Lr = Lr + T * w * erad * scattering * cos_nee / epdf;
+                    const float w = power_heuristic(es.pdf, pdf_bsdf);
+                    nee = T * w * es.radiance * scattering * cos_nee / es.pdf;
                 }
-                const BsdfSample bs = bsdf_sample_in_frame(d, normal, frame, wo, mat, rng);
-                bool finished = false;
+                const BsdfSample bs = bsdf_sample_in_frame(d, surf.normal, frame, wo, mat, rng);
+                bool finished = false, nee_counts = want_shadow;
                 if (bs.dir.x == 0.0f && bs.dir.y == 0.0f && bs.dir.z == 0.0f) {
-                    Lr = bs.scattering;
+                    Lr = bs.scattering; // the shader's debug colours overwrite the radiance, NEE term included
+                    nee_counts = false; // (the shadow ray is still cast, as in the shader)
                     finished = true;
                 } else if (bs.pdf <= 0.0f) {
                     finished = true;
                 } else {
-                    const float c = fmax_(0.0f, dot(normal, bs.dir));
+                    const float c = fmax_(0.0f, dot(surf.normal, bs.dir));
                     T = T * (bs.scattering * (c / bs.pdf));
                     if (length(T) < 0.001f) finished = true;
                 }
                 if (bounce >= P.max_bounces) finished = true;
-                if (finished) {
-                    float *dst = P.sample_buf + (size_t)out * 3u;
+                if (finished && !want_shadow) {
+                    float *dst = P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u;
                     dst[0] = Lr.x; dst[1] = Lr.y; dst[2] = Lr.z;
                     SET_TAG(slot, TAG_FREE);
                 } else {
-                    SETC(C_LASTPDF, slot, bs.pdf);
-                    SETC(C_TX, slot, T.x); SETC(C_TY, slot, T.y); SETC(C_TZ, slot, T.z);
                     SETC(C_LX, slot, Lr.x); SETC(C_LY, slot, Lr.y); SETC(C_LZ, slot, Lr.z);
-                    COLD(C_RNG, slot) = rng;
-                    COLD(C_BOUNCE, slot) = bounce;
-                    SETH(H_DX, slot, bs.dir.x); SETH(H_DY, slot, bs.dir.y); SETH(H_DZ, slot, bs.dir.z); // origin stays the hit point
+                    if (nee_counts) { SETC(C_NEEX, slot, nee.x); SETC(C_NEEY, slot, nee.y); SETC(C_NEEZ, slot, nee.z); }
+                    if (!finished) {
+                        SETC(C_LASTPDF, slot, bs.pdf);
+                        SETC(C_TX, slot, T.x); SETC(C_TY, slot, T.y); SETC(C_TZ, slot, T.z);
+                        COLD(C_RNG, slot) = rng;
+                        COLD(C_BOUNCE, slot) = bounce;
+                        SETH(H_EX, slot, bs.dir.x); SETH(H_EY, slot, bs.dir.y); SETH(H_EZ, slot, bs.dir.z);
+                    }
+                    if (want_shadow) { SETH(H_SX, slot, es.direction.x); SETH(H_SY, slot, es.direction.y); SETH(H_SZ, slot, es.direction.z); }
+                    SETH(H_OX, slot, surf.point.x); SETH(H_OY, slot, surf.point.y); SETH(H_OZ, slot, surf.point.z); // both rays start at the hit point
                     SETH(H_T, slot, RT_INFINITY);
-                    SET_TAG(slot, TAG_TRACE_EXT);
+                    SET_CT(slot, 0u, (want_shadow ? (uint32_t)F_SHADOW : 0u) | (finished ? 0u : (uint32_t)F_EXT) | (nee_counts ? (uint32_t)F_NEE : 0u), TAG_TRACE);
                 }
-                (void)point;
+            }
+        } else {
+            // ---------------- FINISH: the path ended at its last vertex; its shadow ray is back
+            if (on) {
+                const uint32_t ct = HOT(H_CT, slot);
+                V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
+                if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot));
+                float *dst = P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u;
+                dst[0] = Lr.x; dst[1] = Lr.y; dst[2] = Lr.z;
+                SET_TAG(slot, TAG_FREE);
             }
         }
         DBG_STAMP(16 + best); // the stage just run
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
 #undef SETH
 #undef TAG_OF
 #undef SET_TAG
-#undef SET_CUR_TAG
+#undef SET_CT
 #undef COLD
 #undef COLDF
 #undef SETC

@@ -14,7 +14,7 @@ sc = R.Scene.load_toml(util.scene_path(sys.argv[3] if len(sys.argv) > 3 else 'ho
 st = R.State.new(sc, env, 1920, 1080); st.max_bounces = 8
 st.render_range(0, spp); st.synchronize()
 g = st.stats(); c = st.debug_counters().astype(np.float64)
-names = ['GEN', 'TRACE', 'MISS', 'SHADE', 'BSDF']
+names = ['GEN', 'TRACE', 'MISS', 'SHADE', 'FINISH']
 print('kernel variant', os.environ['RSRT_KERNEL'], 'trace kernel %.1f ms' % g['trace_kernel_ms'], 'rays', g['ext_rays'] + g['shadow_rays'])
 for i, n in enumerate(names):
     if c[i]:
