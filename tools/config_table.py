@@ -18,7 +18,9 @@ for label, scene, w, h, spp, mb in [
         ('interactive: house.toml 1920x1080, 1 spp per call (State::render)', 'house', 1920, 1080, 1, 10)]:
     sc = R.Scene.load_toml(util.scene_path(scene))
     st = R.State.new(sc, env, w, h); st.max_bounces = mb
-    st.render_range(0, spp); st.synchronize(); st.stats()
+    for _ in range(1 if spp > 1 else 20):  # warm-up (clocks, allocations)
+        st.render_range(0, spp)
+    st.synchronize(); st.stats()
     n = 3 if spp > 1 else 50
     t = time.perf_counter()
     for i in range(n):
