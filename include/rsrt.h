@@ -52,16 +52,18 @@ typedef struct rsrt_context rsrt_context;
 
 /* flags of rsrt_render */
 enum {
-    /* Default (0): every node and primitive the reference visits is visited, in its order
-     * (shader.wgsl:469-564); only the NEE shadow query, of which the shader reads nothing but
-     * `.did_hit` (:1249), stops at its first hit.  That is exactly result-preserving.
+    /* Default (0): exactly the primitives the reference's unpruned walk tests are tested
+     * (shader.wgsl:469-564), and of equal distances the one it visits first wins; only the NEE
+     * shadow query, of which the shader reads nothing but `.did_hit` (:1249), stops at its
+     * first hit.  That is exactly result-preserving.
      *
      * REFERENCE_TRAVERSAL: also run the shadow query to the end, as the shader literally does. */
     RSRT_FLAG_REFERENCE_TRAVERSAL = 1u,
     /* PRUNE: skip nodes whose slab entry lies beyond the current best hit.  NOT exactly
      * result-preserving: the slab entry t and a primitive's own t are rounded differently, and a
      * primitive a hair closer than the current best can sit in a skipped node.  Measured on
-     * house.toml 1920x1080 x 256 spp: 2 of 5.3e8 paths change (per-channel RMSE 4e-7).  Opt-in. */
+     * house.toml 1920x1080 x 256 spp: 2 of 5.3e8 paths change (per-channel RMSE 4e-7).  Opt-in;
+     * honoured by the tree-walk traversals only (scenes of up to 64 primitives are not walked). */
     RSRT_FLAG_PRUNE = 2u
 };
 
