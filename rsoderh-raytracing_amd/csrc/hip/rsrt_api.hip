@@ -67,13 +67,12 @@ __device__ __forceinline__ SceneView<true> make_view<true>(const DevScene &sc)
     v.o_fbs = v.o_mats + 4u * sc.n_materials;
     v.o_fbp = v.o_fbs + 4u * sc.n_spheres;
     v.o_flat = v.o_fbp + 4u * sc.n_planes;
-    v.n_flat = sc.flat_ok ? sc.n_leaves : 0u;
     return v;
 }
 template <>
 __device__ __forceinline__ SceneView<false> make_view<false>(const DevScene &sc)
 {
-    return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.escape, sc.flat_leaves, sc.flat_rank};
+    return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.escape, sc.flat_leaves};
 }
 
 // Copies the scene image into LDS (the arrays are contiguous in one device allocation, in the order
@@ -381,24 +380,22 @@ struct Env {
 
 // Kernel variants (RSRT_KERNEL): 0 = lockstep megakernel (first kernel); 1, 2 = stage-scheduled wave-pool kernel
 // with 192 / 160 path slots per wave (160: five workgroups per CU fit in LDS).
-#define RT_N_VARIANTS 4
-static const uint32_t kVariantPool[RT_N_VARIANTS] = {0, 192, 160, 128};
+#define RT_N_VARIANTS 3
+static const uint32_t kVariantPool[RT_N_VARIANTS] = {0, 192, 160};
 template <bool LDS, uint32_t POOL>
 static const void *pool_function(int trav)
 {
     switch (trav) {
     case 0: return reinterpret_cast<const void *>(&rt_render_pool_kernel<LDS, POOL, 0>);
     case 1: return reinterpret_cast<const void *>(&rt_render_pool_kernel<LDS, POOL, 1>);
-    case 2: return reinterpret_cast<const void *>(&rt_render_pool_kernel<LDS, POOL, 2>);
-    default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<LDS, POOL, 3>);
+    default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<LDS, POOL, 2>);
     }
 }
 static const void *variant_function(int kv, bool lds, int trav)
 {
     if (kv == 0) return lds ? reinterpret_cast<const void *>(&rt_render_kernel<true>) : reinterpret_cast<const void *>(&rt_render_kernel<false>);
     if (kv == 1) return lds ? pool_function<true, 192>(trav) : pool_function<false, 192>(trav);
-    if (kv == 2) return lds ? pool_function<true, 160>(trav) : pool_function<false, 160>(trav);
-    return lds ? pool_function<true, 128>(trav) : pool_function<false, 128>(trav);
+    return lds ? pool_function<true, 160>(trav) : pool_function<false, 160>(trav);
 }
 
 struct rsrt_context {
@@ -435,7 +432,7 @@ struct rsrt_context {
     unsigned long long base_counts[3] = {0, 0, 0};
     uint32_t cum_launches = 0, base_launches = 0;
     std::vector<hipEvent_t> event_pool;
-    int blocks_per_cu[8][RT_N_VARIANTS] = {}; // [lds * 4 + traversal][kernel variant]
+    int blocks_per_cu[6][RT_N_VARIANTS] = {}; // [lds * 3 + traversal][kernel variant]
     int kernel_variant = 2; // index into kVariantPool
     int max_traversal = 2; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
     uint32_t trace_budget = 12; // traversal steps per TRACE invocation before a ray is re-queued
@@ -617,7 +614,7 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
         return RSRT_ERR_HIP;
     }
     for (int kv = 0; kv < RT_N_VARIANTS; kv++)
-        for (int m = 0; m < 8; m++) (void)hipFuncSetAttribute(variant_function(kv, m >= 4, m % 4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int m = 0; m < 6; m++) (void)hipFuncSetAttribute(variant_function(kv, m >= 3, m % 3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *kv = getenv("RSRT_KERNEL")) { // see kVariantPool
         int v = atoi(kv);
         if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
@@ -853,7 +850,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.typed_leaves = typed_leaves ? 1u : 0u;
     const size_t stack_bytes = (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t);
     if (stack_bytes > 128 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh depth %u exceeds the supported traversal stack", depth);
-    sc.lds_float4s = (img.size() * sizeof(float4) <= 24 * 1024) ? (uint32_t)img.size() : 0u; // LDS image only while it leaves room for the path pools
+    sc.lds_float4s = (n_f4 * sizeof(float4) <= 24 * 1024) ? (uint32_t)n_f4 : 0u; // LDS image only while it leaves room for the path pools
     ctx->scene_ready = true;
     return RSRT_OK;
 }
@@ -1039,13 +1036,13 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const bool lds = P.scene.lds_float4s != 0;
     const int kv = ctx->kernel_variant;
     const uint32_t pool = kVariantPool[kv];
-    const int trav = (ctx->max_traversal >= 2 && P.scene.flat_ok) ? std::min(ctx->max_traversal, 3) : ((ctx->max_traversal >= 1 && P.scene.typed_leaves) ? 1 : 0);
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
-                                : scene_bytes + (size_t)(RT_BLOCK / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + (trav == 3 ? 128u + RT_PAIR_CAP / 2u : 64u));
+                                : scene_bytes + (size_t)(RT_BLOCK / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
+    const int trav = (ctx->max_traversal >= 2 && P.scene.flat_ok) ? 2 : ((ctx->max_traversal >= 1 && P.scene.typed_leaves) ? 1 : 0);
     const void *kfn = variant_function(kv, lds, trav);
-    int &bpc = ctx->blocks_per_cu[(lds ? 4 : 0) + trav][kv];
+    int &bpc = ctx->blocks_per_cu[(lds ? 3 : 0) + trav][kv];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, RT_BLOCK, smem);

@@ -81,10 +81,9 @@ extern __shared__ float4 rt_smem[];
 
 template <>
 struct SceneView<true> {
-    uint32_t o_nodes, o_prims, o_esc, o_trin, o_mats, o_fbs, o_fbp, o_flat, n_flat;
+    uint32_t o_nodes, o_prims, o_esc, o_trin, o_mats, o_fbs, o_fbp, o_flat;
     RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
     RT_DEV float4 flat(uint32_t i) const { return rt_smem[o_flat + i]; }
-    RT_DEV uint32_t rank(uint32_t i) const { return reinterpret_cast<const uint8_t *>(rt_smem + o_flat + 2u * n_flat)[i]; } // follows the leaves
     RT_DEV float4 prim(uint32_t i) const { return rt_smem[o_prims + i]; }
     RT_DEV float4 trin(uint32_t i) const { return rt_smem[o_trin + i]; }
     RT_DEV float4 mat(uint32_t i) const { return rt_smem[o_mats + i]; }
@@ -100,10 +99,8 @@ struct SceneView<true> {
 template <>
 struct SceneView<false> {
     const float4 *nodes, *prims, *tri_normals, *materials, *fb_spheres, *fb_planes, *escape, *flat_leaves;
-    const uint32_t *flat_rank;
     RT_DEV float4 node(uint32_t i) const { return nodes[i]; }
     RT_DEV float4 flat(uint32_t i) const { return flat_leaves[i]; }
-    RT_DEV uint32_t rank(uint32_t i) const { return reinterpret_cast<const uint8_t *>(flat_rank)[i]; }
     RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
     RT_DEV float4 trin(uint32_t i) const { return tri_normals[i]; }
     RT_DEV float4 mat(uint32_t i) const { return materials[i]; }
@@ -991,119 +988,6 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
         RT_FLAT_ACCEPT(t, rec)
         if (better & anyhit) tri_m = pl_m = sp_m = 0ull;
     }
-    while (pl_m != 0ull) {
-        DBG_WAVE_TICK(15);
-        DBG_ADD(13, 1);
-        const uint32_t rec = (uint32_t)__builtin_ctzll(pl_m);
-        pl_m &= pl_m - 1ull;
-        const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u), r3 = S.prim(4u * rec + 3u);
-        const float t = plane_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), v3(r3.x, r3.y, r3.z));
-        RT_FLAT_ACCEPT(t, rec)
-        if (better & anyhit) pl_m = sp_m = 0ull;
-    }
-    while (sp_m != 0ull) {
-        DBG_WAVE_TICK(28);
-        DBG_ADD(13, 1);
-        const uint32_t rec = (uint32_t)__builtin_ctzll(sp_m);
-        sp_m &= sp_m - 1ull;
-        const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u);
-        const float t = sphere_t(o, d, v3(r0.x, r0.y, r0.z), r1.y);
-        RT_FLAT_ACCEPT(t, rec)
-        if (better & anyhit) sp_m = 0ull;
-    }
-#undef RT_FLAT_ACCEPT
-}
-
-// ------------------------------------------------------------------ flat traversal, triangles tested as a team
-// trace_flat's triangle loop runs at ~40 % of the lanes: rays meet different numbers of triangles.  With the
-// record masks of all 64 rays known before the first test, the wave can share the tests out evenly: every lane
-// appends (owner lane, octant, record) for each set bit of its triangle mask to one list in LDS at the
-// position an exclusive prefix sum of the counts assigns it (no ballots: one scan, then each lane walks its
-// own mask), the list is drained 64 pairs at a time — lane i tests pair i with the owner's ray, fetched by
-// ds_bpermute — and results meet in one 64-bit key per ray, merged with ds_min_u64:
-//     key = f32 bits of t << 32 | visiting rank << 8 | record      (positive floats order like integers)
-// so min(key) is "smallest t, and of equal t the record the reference visits first".  Planes and spheres (a
-// fifth of the tests) follow in the lane-local loops.  ALL 64 lanes must call this (lanes without a ray pass
-// valid = false): they test pairs too.
-#define RT_PAIR_CAP 256u // pairs per list window (16-bit entries); more are handled in further windows
-
-RT_DEV float lane_read(uint32_t src_lane, float v) { return as_f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)as_u(v))); }
-
-template <class View>
-RT_DEV void trace_flat_coop(DBG_DECL const View &S, const DevScene &sc, uint32_t lane, bool valid, V3 o, V3 d, V3 inv, bool anyhit,
-                            unsigned long long *keys, uint16_t *pairs, Hit &h)
-{
-    uint32_t all_lo = 0u, all_hi = 0u;
-#pragma unroll 1
-    for (uint32_t L = 0; L < sc.n_leaves; L++) {
-        DBG_WAVE_TICK(10);
-        DBG_ADD(11, 1);
-        const float4 n0 = S.flat(2u * L), n1 = S.flat(2u * L + 1u);
-        const float ax = (n0.x - o.x) * inv.x, bx = (n1.x - o.x) * inv.x;
-        const float ay = (n0.y - o.y) * inv.y, by = (n1.y - o.y) * inv.y;
-        const float az = (n0.z - o.z) * inv.z, bz = (n1.z - o.z) * inv.z;
-        const float t_0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz)), 0.0f);
-        const float t_1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz)), RT_INFINITY);
-        const bool miss = (t_0 > t_1) | !valid;
-        all_lo |= miss ? 0u : as_u(n0.w);
-        all_hi |= miss ? 0u : as_u(n1.w);
-    }
-    const unsigned long long all_m = ((unsigned long long)all_hi << 32) | all_lo;
-    const unsigned long long tri_all = ((unsigned long long)sc.tri_mask_hi << 32) | sc.tri_mask_lo;
-    const unsigned long long pl_all = ((unsigned long long)sc.plane_mask_hi << 32) | sc.plane_mask_lo;
-    unsigned long long tri_m = all_m & tri_all, pl_m = all_m & pl_all, sp_m = all_m & ~(tri_all | pl_all);
-    const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
-
-    // ---- triangles: share the (ray, record) pairs out over the wave
-    const uint32_t count = (uint32_t)__popcll(tri_m);
-    uint32_t incl = count;
-#pragma unroll
-    for (uint32_t s = 1; s < 64u; s <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, s);
-        incl += lane >= s ? up : 0u;
-    }
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    uint32_t pos = incl - count; // list position of this lane's next pair
-    keys[lane] = (unsigned long long)as_u(RT_INFINITY) << 32; // "nothing yet": any real hit is smaller
-    for (uint32_t base = 0; base < total; base += RT_PAIR_CAP) {
-        while ((tri_m != 0ull) & (pos < base + RT_PAIR_CAP)) {
-            DBG_WAVE_TICK(14);
-            const uint32_t rec = (uint32_t)__builtin_ctzll(tri_m);
-            tri_m &= tri_m - 1ull;
-            pairs[pos - base] = (uint16_t)((lane << 9) | (octant << 6) | rec);
-            pos++;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t n = min(RT_PAIR_CAP, total - base);
-        for (uint32_t j = 0; j < n; j += 64u) {
-            DBG_WAVE_TICK(12);
-            const bool act = j + lane < n;
-            const uint32_t pr = act ? (uint32_t)pairs[j + lane] : 0u;
-            const uint32_t owner = pr >> 9, oct = (pr >> 6) & 7u, rec = pr & 63u;
-            const V3 ro = v3(lane_read(owner, o.x), lane_read(owner, o.y), lane_read(owner, o.z));
-            const V3 rd = v3(lane_read(owner, d.x), lane_read(owner, d.y), lane_read(owner, d.z));
-            const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u);
-            float u, v;
-            const float t = triangle_t(ro, rd, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), u, v);
-            if (act) DBG_ADD(13, 1);
-            if (act & (t >= 0.0f))
-                __hip_atomic_fetch_min(&keys[owner], ((unsigned long long)as_u(t) << 32) | (S.rank(oct * 64u + rec) << 8) | rec, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    {
-        const unsigned long long key = keys[lane];
-        const float t = as_f((uint32_t)(key >> 32));
-        if (t < RT_INFINITY) { h.t = t; h.ref = (uint32_t)key & 0xffu; }
-        if (anyhit & (t < RT_INFINITY)) pl_m = sp_m = 0ull;
-    }
-    // ---- planes, spheres: lane-local
-#define RT_FLAT_ACCEPT(t, rec)                                                                                         \
-    bool better = ((t) >= 0.0f) & ((t) < h.t);                                                                         \
-    if (((t) == h.t) & (h.t < RT_INFINITY)) better = flat_rank_of(sc, octant, (rec)) < flat_rank_of(sc, octant, h.ref); \
-    h.t = better ? (t) : h.t;                                                                                          \
-    h.ref = better ? (rec) : h.ref;
     while (pl_m != 0ull) {
         DBG_WAVE_TICK(15);
         DBG_ADD(13, 1);

@@ -53,14 +53,11 @@ enum ColdField {
 enum PoolTag { TAG_FREE = 0, TAG_TRACE = 1, TAG_MISS = 2, TAG_SHADE = 3, TAG_FINISH = 4, TAG_IDLE = 5 };
 enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_FINISH = 4, ST_COUNT = 5 };
 
-template <uint32_t POOL, int TRAV>
+template <uint32_t POOL>
 struct PoolLayout {
     static constexpr uint32_t kSlotsPerLane = (POOL + 63u) / 64u;
     static constexpr uint32_t kHotDwords = H_COUNT * POOL;
-    // scratch after the hot columns: the compaction list (64 dwords); TRAV 3 adds 64 u64 keys in front of it and
-    // grows the list area to RT_PAIR_CAP 16-bit pairs (the compaction list is dead by then and shares it)
-    static constexpr uint32_t kKeyDwords = TRAV == 3 ? 128u : 0u;
-    static constexpr uint32_t kListDwords = kKeyDwords + (TRAV == 3 ? RT_PAIR_CAP / 2u : 64u);
+    static constexpr uint32_t kListDwords = 64u;
     static constexpr uint32_t kWaveLdsDwords = kHotDwords + kListDwords;
     static constexpr uint32_t kWaveColdDwords = C_COUNT * POOL;
 };
@@ -71,12 +68,11 @@ RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE
 #define RT_POOL_WAVES_PER_SIMD 4
 #endif
 // TRAV: which traversal TRACE runs — 0 trace_threaded (any BVH), 1 trace_threaded_typed (leaves of <= 8
-// primitives), 2 trace_flat (<= 64 primitive records, nested boxes; rays with a non-finite 1/d fall back to 0),
-// 3 trace_flat_coop (as 2, triangles tested by the wave as a team)
+// primitives), 2 trace_flat (<= 64 primitive records, nested boxes; rays with a non-finite 1/d fall back to 0)
 template <bool LDS, uint32_t POOL, int TRAV>
 __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
 {
-    typedef PoolLayout<POOL, TRAV> L;
+    typedef PoolLayout<POOL> L;
     const DevScene &sc = P.scene;
     if (LDS) stage_scene_lds(sc);
     const SceneView<LDS> S = make_view<LDS>(sc);
@@ -84,7 +80,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
     const uint32_t wave = threadIdx.x / RT_WAVE;
     uint32_t *const lds32 = reinterpret_cast<uint32_t *>(rt_smem + sc.lds_float4s);
     uint32_t *const W = lds32 + wave * L::kWaveLdsDwords; // this wave's hot columns
-    uint32_t *const list = W + L::kHotDwords + L::kKeyDwords;
+    uint32_t *const list = W + L::kHotDwords;
     uint32_t *const G = P.cold_state + (size_t)(blockIdx.x * (RT_BLOCK / RT_WAVE) + wave) * L::kWaveColdDwords; // cold columns
     const bool prune = (P.flags & RSRT_FLAG_PRUNE) != 0;
     const bool anyhit_shadow = !(P.flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
@@ -199,37 +195,6 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
                     if (lane + 64u * k < POOL && TAG_OF(lane + 64u * k) == TAG_FREE) SET_TAG(lane + 64u * k, TAG_IDLE);
             }
-        } else if (best == ST_TRACE && TRAV == 3) {
-            // ---------------- TRACE, flat traversal with the triangle tests shared out over the wave.  ALL 64
-            // lanes run this block (rt_device.h, trace_flat_coop): lanes without a ray still test pairs.
-            const uint32_t ct = on ? HOT(H_CT, slot) : 0u;
-            const bool shadow = (ct & F_SHADOW) != 0u;
-            const uint32_t dcol = shadow ? (uint32_t)H_SX : (uint32_t)H_EX;
-            const V3 o = on ? v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot)) : v3(0.0f, 0.0f, 0.0f);
-            const V3 d = on ? v3(HOTF(dcol, slot), HOTF(dcol + 1u, slot), HOTF(dcol + 2u, slot)) : v3(1.0f, 1.0f, 1.0f);
-            __builtin_amdgcn_wave_barrier(); // every lane has read its slot from `list`, which the pair list now reuses
-            Hit h;
-            h.src = SRC_BVH; h.t = RT_INFINITY; h.ref = 0; h.u = h.v = 0.0f;
-            const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
-            const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f; // NaN if anything is infinite / NaN
-            if (on && !(finite == 0.0f)) { // rare: this ray keeps the tree walk
-                uint32_t cur = 0u;
-                trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, 0xffffffffu, cur, h);
-            }
-            trace_flat_coop(DBG_ARG S, sc, lane, on && finite == 0.0f, o, d, inv, shadow && anyhit_shadow,
-                            reinterpret_cast<unsigned long long *>(W + L::kHotDwords), reinterpret_cast<uint16_t *>(list), h);
-            if (on) {
-                if (shadow) {
-                    n_shadow++;
-                    SETH(H_T, slot, RT_INFINITY);
-                    const uint32_t fl = (ct & (F_EXT | F_NEE)) | (h.t < RT_INFINITY ? (uint32_t)F_OCCLUDED : 0u);
-                    SET_CT(slot, 0u, fl, (ct & F_EXT) ? TAG_TRACE : TAG_FINISH);
-                } else {
-                    n_ext++;
-                    SETH(H_T, slot, h.t);
-                    SET_CT(slot, h.ref, ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
-                }
-            }
         } else if (best == ST_TRACE) {
             // ---------------- TRACE: one ray of the slot from its vertex O — the shadow ray (direction S, any
             // hit) while one is pending, else the extension ray (direction E, closest hit): cast_ray_bvh
@@ -245,7 +210,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 h.src = SRC_BVH;
                 h.t = HOTF(H_T, slot); h.ref = 0; h.u = h.v = 0.0f; // ref of an earlier call stays in the cold column unless beaten
                 const float t_in = h.t;
-                if (TRAV >= 2) {
+                if (TRAV == 2) {
                     const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
                     // 0 * x is NaN exactly when x is infinite or NaN (an overflowing sum only sends a ray the long way round)
                     const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f;
@@ -263,7 +228,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 const bool done = cur == RT_END;
                 if (!done) { // to be resumed: best t and cursor
                     SETH(H_T, slot, h.t);
-                    if (TRAV < 2 && !shadow && h.t < t_in) COLD(C_REF, slot) = h.ref;
+                    if (TRAV != 2 && !shadow && h.t < t_in) COLD(C_REF, slot) = h.ref;
                     SET_CT(slot, cur, ct & CT_FLAGS, TAG_TRACE);
                 } else if (shadow) {
                     n_shadow++;
@@ -273,9 +238,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 } else {
                     n_ext++;
                     SETH(H_T, slot, h.t);
-                    if (TRAV < 2 && h.t < t_in) COLD(C_REF, slot) = h.ref; // this call found a closer hit
+                    if (TRAV != 2 && h.t < t_in) COLD(C_REF, slot) = h.ref; // this call found a closer hit
                     // the flat traversal's records fit the idle cursor bits: no cold column
-                    SET_CT(slot, TRAV >= 2 ? h.ref : 0u, ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
+                    SET_CT(slot, TRAV == 2 ? h.ref : 0u, ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
                 }
             }
         } else if (best == ST_MISS) {
@@ -298,7 +263,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 }
                 if (h.did_hit()) { // SHADE takes it from here (and settles the pending NEE term)
                     SETH(H_T, slot, h.t);
-                    if (TRAV >= 2) {
+                    if (TRAV == 2) {
                         SET_CT(slot, h.ref | (h.src << 6), ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
                     } else {
                         COLD(C_REF, slot) = h.ref | (h.src << 30);
@@ -327,7 +292,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_po
                 const V3 d = v3(HOTF(H_EX, slot), HOTF(H_EY, slot), HOTF(H_EZ, slot));
                 Hit h;
                 h.t = HOTF(H_T, slot);
-                if (TRAV >= 2) {
+                if (TRAV == 2) {
                     const uint32_t hr = ct >> CT_SHIFT;
                     h.ref = hr & 63u; h.src = hr >> 6;
                 } else {
