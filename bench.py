@@ -201,17 +201,19 @@ def main():
             owned_pixels = int(partition.owned_mask(W, H, rank, world).sum())
             algo = per_path * paths_per_launch + 16.0 * owned_pixels
             achieved = algo / (trace_ms_per_launch * 1e-3) / 1e9
-            traffic = None  # PMC counters cannot be read from inside this process: committed rocprofv3 measurement
+            traffic = issue = None  # PMC counters cannot be read from inside this process: committed rocprofv3 measurement
             if std_cfg and world == 1 and spp == 256 and os.path.exists(TRAFFIC_FILE):
                 with open(TRAFFIC_FILE) as f:
                     tj = json.load(f)
                 traffic = (tj.get("fetch_bytes_per_launch") or 0) + (tj.get("write_bytes_per_launch") or 0)
+                issue = tj.get("issue")  # what actually bounds the kernel: VALU issue (same rocprofv3 run)
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "kernel": "rt_render_pool_kernel", "launch_ms": trace_ms_per_launch,
                         "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_per_path": per_path,
-                        "sample_buffer_bytes_per_launch": 24.0 * paths_per_launch,
-                        "note": "working set (5.5 KB scene in LDS + 64 MiB environment, MALL-resident) is cache-resident by "
-                                "construction; FP32 VALU + divergence bound, see DESIGN.md"}
+                        "sample_buffer_bytes_per_launch": 24.0 * paths_per_launch, "valu_issue": issue,
+                        "note": "working set (10 KB scene image in LDS + 64 MiB environment, MALL-resident) is cache-resident by "
+                                "construction, so the fraction of the HBM peak exceeds 1; the kernel is bound by FP32 VALU issue "
+                                "and lane divergence (valu_issue, DESIGN.md section 5)"}
         result = {"metric": "Mrays/s, house.toml 1920x1080 256spp 8-bounce", "value": value, "unit": "Mrays/s",
                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
