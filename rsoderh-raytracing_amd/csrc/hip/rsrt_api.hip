@@ -58,11 +58,11 @@ __device__ __forceinline__ SceneView<LDS> make_view(const DevScene &sc);
 template <>
 __device__ __forceinline__ SceneView<true> make_view<true>(const DevScene &sc)
 {
-    SceneView<true> v;
+    SceneView<true> v; // image order: nodes | escape links | primitive records | triangle normals | materials | fallback records | flat leaves
     v.o_nodes = 0;
-    v.o_prims = v.o_nodes + 2u * sc.n_nodes;
-    v.o_esc = v.o_prims + 4u * sc.n_prims;
-    v.o_trin = v.o_esc + (8u * sc.n_nodes + 3u) / 4u;
+    v.o_esc = v.o_nodes + 2u * sc.n_nodes;
+    v.o_prims = v.o_esc + (8u * sc.n_nodes + 3u) / 4u;
+    v.o_trin = v.o_prims + 4u * sc.n_prims;
     v.o_mats = v.o_trin + 3u * sc.n_tris;
     v.o_fbs = v.o_mats + 4u * sc.n_materials;
     v.o_fbp = v.o_fbs + 4u * sc.n_spheres;
@@ -73,6 +73,11 @@ template <>
 __device__ __forceinline__ SceneView<false> make_view<false>(const DevScene &sc)
 {
     return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.escape, sc.flat_leaves};
+}
+
+__device__ __forceinline__ SceneViewHybrid make_view_hybrid(const DevScene &sc)
+{
+    return SceneViewHybrid{0u, 2u * sc.n_nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes};
 }
 
 // Copies the scene image into LDS (the arrays are contiguous in one device allocation, in the order
@@ -382,20 +387,22 @@ struct Env {
 // with 192 / 160 path slots per wave (160: five workgroups per CU fit in LDS).
 #define RT_N_VARIANTS 3
 static const uint32_t kVariantPool[RT_N_VARIANTS] = {0, 192, 160};
-template <bool LDS, uint32_t POOL>
+template <int SV, uint32_t BLOCK, uint32_t POOL>
 static const void *pool_function(int trav)
 {
     switch (trav) {
-    case 0: return reinterpret_cast<const void *>(&rt_render_pool_kernel<LDS, POOL, 0>);
-    case 1: return reinterpret_cast<const void *>(&rt_render_pool_kernel<LDS, POOL, 1>);
-    default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<LDS, POOL, 2>);
+    case 0: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 0>);
+    case 1: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 1>);
+    default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 2>);
     }
 }
-static const void *variant_function(int kv, bool lds, int trav)
+// sv: 0 scene in global memory, 1 whole image in LDS, 2 hybrid (nodes + escape links in LDS, 1024-thread workgroups)
+static const void *variant_function(int kv, int sv, int trav)
 {
-    if (kv == 0) return lds ? reinterpret_cast<const void *>(&rt_render_kernel<true>) : reinterpret_cast<const void *>(&rt_render_kernel<false>);
-    if (kv == 1) return lds ? pool_function<true, 192>(trav) : pool_function<false, 192>(trav);
-    return lds ? pool_function<true, 160>(trav) : pool_function<false, 160>(trav);
+    if (kv == 0) return sv == 1 ? reinterpret_cast<const void *>(&rt_render_kernel<true>) : reinterpret_cast<const void *>(&rt_render_kernel<false>);
+    if (sv == 2) return pool_function<2, 1024, 160>(std::min(trav, 1));
+    if (kv == 1) return sv == 1 ? pool_function<1, RT_BLOCK, 192>(trav) : pool_function<0, RT_BLOCK, 192>(trav);
+    return sv == 1 ? pool_function<1, RT_BLOCK, 160>(trav) : pool_function<0, RT_BLOCK, 160>(trav);
 }
 
 struct rsrt_context {
@@ -432,9 +439,10 @@ struct rsrt_context {
     unsigned long long base_counts[3] = {0, 0, 0};
     uint32_t cum_launches = 0, base_launches = 0;
     std::vector<hipEvent_t> event_pool;
-    int blocks_per_cu[6][RT_N_VARIANTS] = {}; // [lds * 3 + traversal][kernel variant]
+    int blocks_per_cu[9][RT_N_VARIANTS] = {}; // [scene view * 3 + traversal][kernel variant]
     int kernel_variant = 2; // index into kVariantPool
     int max_traversal = 2; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
+    bool allow_hybrid = true;
     uint32_t trace_budget = 12; // traversal steps per TRACE invocation before a ray is re-queued
     unsigned long long debug_words[32] = {0};
 };
@@ -614,11 +622,12 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
         return RSRT_ERR_HIP;
     }
     for (int kv = 0; kv < RT_N_VARIANTS; kv++)
-        for (int m = 0; m < 6; m++) (void)hipFuncSetAttribute(variant_function(kv, m >= 3, m % 3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int m = 0; m < 9; m++) (void)hipFuncSetAttribute(variant_function(kv, m / 3, m % 3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *kv = getenv("RSRT_KERNEL")) { // see kVariantPool
         int v = atoi(kv);
         if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
     }
+    if (const char *hy = getenv("RSRT_HYBRID")) ctx->allow_hybrid = atoi(hy) != 0; // 0: mid-size scenes read everything from global memory (A/B)
     if (const char *ty = getenv("RSRT_TRAVERSAL")) ctx->max_traversal = atoi(ty); // cap: 0 generic tree walk, 1 typed leaf loops, 2 flat small-scene loop (A/B)
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_cast_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -790,6 +799,10 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         }
         p[1] = f4(nd.bounds_max[0], nd.bounds_max[1], nd.bounds_max[2], u2f(nd.primitives_len | (hi << 16)));
     }
+    float4 *p_esc = p;
+    memcpy(p_esc, escape.data(), escape.size() * sizeof(uint32_t));
+    p += esc_f4;
+    const size_t traversal_head_f4 = (size_t)(p - img.data()); // nodes | escape links: what the hybrid view keeps in LDS
     float4 *p_prims = p;
     for (uint32_t i = 0; i < n_primitives; i++, p += 4) {
         const rsrt_primitive_info &pi = primitives[i];
@@ -797,9 +810,6 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         else if (pi.primitive_type == 1) make_plane_record(planes[pi.index], p);
         else make_triangle_record(triangles[pi.index], pi.index, vertices, p);
     }
-    float4 *p_esc = p;
-    memcpy(p_esc, escape.data(), escape.size() * sizeof(uint32_t));
-    p += esc_f4;
     float4 *p_trin = p;
     for (uint32_t i = 0; i < n_triangles; i++, p += 3) {
         const float *a = normals[triangles[i].normal_0].v, *b = normals[triangles[i].normal_1].v, *c = normals[triangles[i].normal_2].v;
@@ -850,7 +860,12 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.typed_leaves = typed_leaves ? 1u : 0u;
     const size_t stack_bytes = (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t);
     if (stack_bytes > 128 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh depth %u exceeds the supported traversal stack", depth);
-    sc.lds_float4s = (n_f4 * sizeof(float4) <= 24 * 1024) ? (uint32_t)n_f4 : 0u; // LDS image only while it leaves room for the path pools
+    sc.lds_float4s = (n_f4 * sizeof(float4) <= 24 * 1024) ? (uint32_t)n_f4 : 0u; // whole image in LDS only while it leaves room for the path pools
+    sc.lds_hybrid = 0;
+    if (sc.lds_float4s == 0 && traversal_head_f4 * sizeof(float4) <= 40 * 1024) { // mid-size: nodes + escape links, one big workgroup per CU
+        sc.lds_float4s = (uint32_t)traversal_head_f4;
+        sc.lds_hybrid = 1;
+    }
     ctx->scene_ready = true;
     return RSRT_OK;
 }
@@ -1033,26 +1048,28 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     }
     P.sample_buf = ctx->sample_buf;
 
-    const bool lds = P.scene.lds_float4s != 0;
     const int kv = ctx->kernel_variant;
-    const uint32_t pool = kVariantPool[kv];
+    int sv = P.scene.lds_float4s == 0 ? 0 : (P.scene.lds_hybrid ? 2 : 1);
+    if (sv == 2 && (kv == 0 || !ctx->allow_hybrid)) { sv = 0; P.scene.lds_float4s = 0; } // the first kernel has no hybrid form
+    const uint32_t pool = sv == 2 ? 160u : kVariantPool[kv];
+    const uint32_t block = sv == 2 ? 1024u : (uint32_t)RT_BLOCK;
+    const int trav = (ctx->max_traversal >= 2 && P.scene.flat_ok) ? 2 : ((ctx->max_traversal >= 1 && P.scene.typed_leaves) ? 1 : 0);
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
-                                : scene_bytes + (size_t)(RT_BLOCK / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
+                                : scene_bytes + (size_t)(block / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
-    const int trav = (ctx->max_traversal >= 2 && P.scene.flat_ok) ? 2 : ((ctx->max_traversal >= 1 && P.scene.typed_leaves) ? 1 : 0);
-    const void *kfn = variant_function(kv, lds, trav);
-    int &bpc = ctx->blocks_per_cu[(lds ? 3 : 0) + trav][kv];
+    const void *kfn = variant_function(kv, sv, trav);
+    int &bpc = ctx->blocks_per_cu[sv * 3 + trav][kv];
     if (bpc == 0) {
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, RT_BLOCK, smem);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, (int)block, smem);
         if (e != hipSuccess || nb <= 0) nb = 1;
         bpc = std::min(nb, 8);
         if (const char *o = getenv("RSRT_BLOCKS_PER_CU")) { int v = atoi(o); if (v > 0) bpc = std::min(bpc, v); } // experiment knob
     }
 
     if (kv != 0) { // cold path-state arena: one block of columns per wave that can be resident
-        const size_t need_cold = (size_t)ctx->cus * bpc * (RT_BLOCK / RT_WAVE) * C_COUNT * pool * sizeof(uint32_t);
+        const size_t need_cold = (size_t)ctx->cus * bpc * (block / RT_WAVE) * C_COUNT * pool * sizeof(uint32_t);
         if (need_cold > ctx->cold_bytes) {
             HIP_TRY(ctx, hipStreamSynchronize(stream));
             if (ctx->cold_state) { (void)hipFree(ctx->cold_state); ctx->cold_state = nullptr; ctx->cold_bytes = 0; }
@@ -1073,7 +1090,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
             // partitioned frame — so that every resident wave still gets >= ~32 chunks and the tail,
             // where waves run out of work at different times, stays a few percent.
             {
-                const uint64_t waves = (uint64_t)ctx->cus * bpc * (RT_BLOCK / RT_WAVE);
+                const uint64_t waves = (uint64_t)ctx->cus * bpc * (block / RT_WAVE);
                 const uint64_t want_chunks = 32ull * waves;
                 const uint64_t total_tile_samples = (uint64_t)P.n_owned_tiles * P.sample_count;
                 uint64_t spc = total_tile_samples / std::max<uint64_t>(want_chunks, 1);
@@ -1093,10 +1110,11 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
             P.n_chunks = (uint32_t)n_chunks;
             HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, sizeof(unsigned int), stream));
             const uint32_t waves_wanted = (uint32_t)std::min<uint64_t>(n_chunks, 0x7fffffffull);
-            uint32_t grid = std::min<uint32_t>((waves_wanted + 3) / 4, (uint32_t)(ctx->cus * bpc));
+            const uint32_t wpb = block / RT_WAVE;
+            uint32_t grid = std::min<uint32_t>((waves_wanted + wpb - 1) / wpb, (uint32_t)(ctx->cus * bpc));
             grid = std::max(grid, 1u);
             void *kargs[] = {&P};
-            HIP_TRY(ctx, hipLaunchKernel(kfn, dim3(grid), dim3(RT_BLOCK), kargs, smem, stream));
+            HIP_TRY(ctx, hipLaunchKernel(kfn, dim3(grid), dim3(block), kargs, smem, stream));
             ctx->cum_launches++;
         } else {
             HIP_TRY(ctx, hipMemsetAsync(ctx->sample_buf, 0, per_sample * P.sample_count, stream));

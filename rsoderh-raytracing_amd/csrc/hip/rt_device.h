@@ -56,6 +56,7 @@ struct DevScene {
     uint32_t n_nodes, n_prims, n_tris, n_materials, n_spheres, n_planes;
     uint32_t stack_entries;    // per-lane traversal stack entries (tree depth + 1)
     uint32_t lds_float4s;      // float4 count of the LDS image (0 = scene stays in global memory)
+    uint32_t lds_hybrid;       // the LDS image is only nodes | escape links (SceneViewHybrid, one 1024-thread workgroup per CU)
     uint32_t typed_leaves;     // no leaf has more than 8 primitives: leaf node words carry triangle / plane masks (trace_threaded_typed)
     // flat small-scene traversal (trace_flat): at most 64 primitive records, every child box inside its parent's
     uint32_t flat_ok, n_leaves;
@@ -110,6 +111,24 @@ struct SceneView<false> {
         return prims[(src == SRC_FB_SPHERE ? ds : 0) + (src == SRC_FB_PLANE ? dp : 0) + (ptrdiff_t)i];
     }
     RT_DEV uint32_t esc(uint32_t i) const { return reinterpret_cast<const uint32_t *>(escape)[i]; }
+};
+
+// Mid-size scenes (suzanne: 97 KB of traversal data): what every box step touches — nodes and escape links —
+// in LDS, shared by ONE 1024-thread workgroup per CU; primitive records and the shading arrays in global memory.
+struct SceneViewHybrid {
+    uint32_t o_nodes, o_esc;
+    const float4 *prims, *tri_normals, *materials, *fb_spheres, *fb_planes;
+    RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
+    RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
+    RT_DEV float4 trin(uint32_t i) const { return tri_normals[i]; }
+    RT_DEV float4 mat(uint32_t i) const { return materials[i]; }
+    RT_DEV float4 flat(uint32_t) const { return float4{0.0f, 0.0f, 0.0f, 0.0f}; } // (the flat traversal needs the whole image in LDS)
+    RT_DEV float4 rec(uint32_t src, uint32_t i) const
+    {
+        const ptrdiff_t ds = fb_spheres - prims, dp = fb_planes - prims; // all three live in one allocation
+        return prims[(src == SRC_FB_SPHERE ? ds : 0) + (src == SRC_FB_PLANE ? dp : 0) + (ptrdiff_t)i];
+    }
+    RT_DEV uint32_t esc(uint32_t i) const { return reinterpret_cast<const uint32_t *>(rt_smem + o_esc)[i]; }
 };
 
 // ------------------------------------------------------------------ RNG (shader.wgsl:605-631)

@@ -69,19 +69,26 @@ RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE
 #endif
 // TRAV: which traversal TRACE runs — 0 trace_threaded (any BVH), 1 trace_threaded_typed (leaves of <= 8
 // primitives), 2 trace_flat (<= 64 primitive records, nested boxes; rays with a non-finite 1/d fall back to 0)
-template <bool LDS, uint32_t POOL, int TRAV>
-__global__ __launch_bounds__(RT_BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
+// SV: where the scene is read from — 0 global memory, 1 the whole image in LDS (256-thread workgroups, several per
+// CU), 2 nodes + escape links in LDS (SceneViewHybrid; BLOCK = 1024: one workgroup per CU shares the copy)
+template <int SV> struct PoolView;
+template <> struct PoolView<0> { typedef SceneView<false> type; static __device__ __forceinline__ type make(const DevScene &sc) { return make_view<false>(sc); } };
+template <> struct PoolView<1> { typedef SceneView<true> type; static __device__ __forceinline__ type make(const DevScene &sc) { return make_view<true>(sc); } };
+template <> struct PoolView<2> { typedef SceneViewHybrid type; static __device__ __forceinline__ type make(const DevScene &sc) { return make_view_hybrid(sc); } };
+
+template <int SV, uint32_t BLOCK, uint32_t POOL, int TRAV>
+__global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
 {
     typedef PoolLayout<POOL> L;
     const DevScene &sc = P.scene;
-    if (LDS) stage_scene_lds(sc);
-    const SceneView<LDS> S = make_view<LDS>(sc);
+    if (SV != 0) stage_scene_lds(sc);
+    const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t wave = threadIdx.x / RT_WAVE;
     uint32_t *const lds32 = reinterpret_cast<uint32_t *>(rt_smem + sc.lds_float4s);
     uint32_t *const W = lds32 + wave * L::kWaveLdsDwords; // this wave's hot columns
     uint32_t *const list = W + L::kHotDwords;
-    uint32_t *const G = P.cold_state + (size_t)(blockIdx.x * (RT_BLOCK / RT_WAVE) + wave) * L::kWaveColdDwords; // cold columns
+    uint32_t *const G = P.cold_state + (size_t)(blockIdx.x * (BLOCK / RT_WAVE) + wave) * L::kWaveColdDwords; // cold columns
     const bool prune = (P.flags & RSRT_FLAG_PRUNE) != 0;
     const bool anyhit_shadow = !(P.flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
     const uint32_t tile_px = P.tile_w * P.tile_h;

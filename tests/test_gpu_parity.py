@@ -460,3 +460,15 @@ def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_en
     same = util.bits(img) == util.bits(ref)
     assert same.all(), (traversal, int((~same).any(axis=2).sum()))
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+
+
+@pytest.mark.parametrize("hybrid", ["1", "0"])
+def test_mid_size_scene_with_nodes_in_lds_or_in_global_memory(hybrid, big_env, monkeypatch):
+    """suzanne (968 triangles): too big for the LDS image; by default its nodes and escape links are staged in LDS
+    for one 1024-thread workgroup per CU (RSRT_HYBRID=0: everything from global memory).  Same bits either way."""
+    monkeypatch.setenv("RSRT_HYBRID", hybrid)
+    sc = R.Scene.load_toml(util.scene_path("suzanne"))
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 120, 68, 0, 4, 10)
+    img, st = gpu_render(sc, big_env, 120, 68, 0, 4, 10)
+    assert np.array_equal(util.bits(img), util.bits(ref))
+    assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
