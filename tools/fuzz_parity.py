@@ -20,6 +20,8 @@ for trial in range(trials):
     rng = np.random.default_rng(seed0 + trial)
     ns, npl = int(rng.integers(0, 6)), int(rng.integers(0, 4))
     nt = int(rng.integers(1, 64 - ns - npl)) if trial % 4 else int(rng.integers(60, 120))  # every 4th: too big for the flat loop
+    if trial % 20 == 10:
+        nt = int(rng.integers(350, 500))  # image > 24 KB: nodes + escape links in LDS, the rest in global memory
     mats = np.zeros(4, T.MATERIAL)
     mats["color"] = rng.uniform(0.05, 1, (4, 3))
     mats["roughness"] = rng.choice([0.0, 0.05, 0.3, 1.0], 4)
