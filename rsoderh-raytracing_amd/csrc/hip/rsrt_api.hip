@@ -517,8 +517,6 @@ void make_material_record(const rsrt_material &m, float4 *r)
     r[3] = f4(kd[0], kd[1], kd[2], 1.0f - ps);
 }
 
-size_t lds_limit_bytes() { return 64 * 1024; }
-
 rsrt_status ensure_accumulator(rsrt_context *ctx, uint32_t w, uint32_t h)
 {
     if (ctx->accum && ctx->acc_w == w && ctx->acc_h == h) return RSRT_OK;
