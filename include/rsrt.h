@@ -147,8 +147,13 @@ rsrt_status rsrt_get_stats(rsrt_context *ctx, rsrt_stats *out);
 /* -- ray-query probe: cast_ray / cast_ray_bvh for a batch of rays (shader.wgsl:469-601) -------
  * Exists for parity tests of traversal + intersection without the RNG: out records are
  * {did_hit u32, distance f32, hit_point 3xf32, normal 3xf32, material_id u32} = 36 bytes.
- * mode 0 = cast_ray (BVH then brute-force fallback), 1 = cast_ray_bvh — both through the production
- * kernel's threaded traversal; mode | 2 = the same through the first kernel's stack traversal. Host pointers. */
+ * mode bit 0: 0 = cast_ray (BVH, then the brute-force fallback), 1 = cast_ray_bvh only;
+ * mode bits 1-2, the traversal: 0 = threaded tree walk, 1 = the first kernel's stack walk, 2 = tree walk with typed leaf
+ *   loops (suzanne in production), 3 = flat loop over the leaf boxes (house, default, cube in production) — the very
+ *   device functions rt_render_pool_kernel's TRACE stage calls; a scene that does not qualify for 2 / 3 is
+ *   RSRT_ERR_INVALID_ARGUMENT;
+ * mode bit 3: read the scene from LDS exactly as the production kernel stages it (whole image, or nodes + escape
+ *   links for mid-size scenes) instead of from global memory.  Host pointers. */
 typedef struct rsrt_hit {
     uint32_t did_hit;
     float distance;
@@ -172,6 +177,10 @@ rsrt_status rsrt_selftest_numerics(rsrt_context *ctx, uint64_t out[4]);
 
 /* Library / device description, for logs: "librsrt <version>; <device name>; <CUs> CUs". */
 const char *rsrt_describe(rsrt_context *ctx);
+/* 16 hex digits: sha256 over the kernel sources this library was compiled from (plus any experiment knob).  The
+ * rocprofv3 summaries under profiles/ carry the id of the library they were taken on; bench.py attaches a profile
+ * to its roofline object only when the ids agree. */
+const char *rsrt_build_id(void);
 
 #ifdef __cplusplus
 }

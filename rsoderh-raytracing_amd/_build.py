@@ -1,6 +1,7 @@
 """In-tree native builds: librsrt_host.so (g++, CPU preprocessing) and librsrt.so (hipcc, gfx950)."""
 import contextlib
 import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -61,20 +62,44 @@ def hipcc_path():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+def _knob_flags():
+    """Experiment knobs (tools/knob_sweep.py, tools/flag_sweep.sh): extra compiler flags / macro overrides."""
+    flags = []
+    if os.environ.get("RSRT_HIPCC_FLAGS"):  # extra compiler flags
+        flags += os.environ["RSRT_HIPCC_FLAGS"].split()
+    if os.environ.get("RSRT_WPS"):  # waves per SIMD the pool kernel is compiled for
+        flags.append("-DRT_POOL_WAVES_PER_SIMD=" + os.environ["RSRT_WPS"])
+    if os.environ.get("RSRT_LEAFQ"):  # leaves a lane holds before the wave tests primitives
+        flags.append("-DRT_LEAFQ=" + os.environ["RSRT_LEAFQ"])
+    return flags
+
+
+def source_id():
+    """sha256 (16 hex digits) over every file that goes into librsrt.so: compiled in as RSRT_BUILD_ID
+    (rsrt_build_id()) and written into the rocprofv3 summaries under profiles/, so that bench.py can tell
+    whether a committed profile was taken on the kernel it is timing."""
+    h = hashlib.sha256()
+    for f in sorted(_deps("hip")):
+        if f.endswith((".h", ".hip", ".hpp")):
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build_hip(force=False, extra_flags=(), instrument=False):
-    """librsrt.so; instrument=True builds the diagnostic twin librsrt_instr.so (-DRT_INSTRUMENT)."""
+    """librsrt.so; instrument=True builds the diagnostic twin librsrt_instr.so (-DRT_INSTRUMENT).
+    With an experiment knob set the build goes to librsrt_exp_<hash of the flags>.so instead: the
+    product library is never overwritten by an experiment."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     target = HIP_LIB.replace(".so", "_instr.so") if instrument else HIP_LIB
     flags = list(extra_flags) + (["-DRT_INSTRUMENT"] if instrument else [])
-    if os.environ.get("RSRT_HIPCC_FLAGS"):  # experiment knob: extra compiler flags
-        flags += os.environ["RSRT_HIPCC_FLAGS"].split()
-        force = True
-    if os.environ.get("RSRT_WPS"):  # experiment knob: waves per SIMD the pool kernel is compiled for
-        flags.append("-DRT_POOL_WAVES_PER_SIMD=" + os.environ["RSRT_WPS"])
-        force = True
-    if os.environ.get("RSRT_LEAFQ"):  # experiment knob: leaves a lane holds before the wave tests primitives
-        flags.append("-DRT_LEAFQ=" + os.environ["RSRT_LEAFQ"])
-        force = True
+    knobs = _knob_flags()
+    if knobs:
+        flags += knobs
+        target = target.replace(".so", "_exp_%s.so" % hashlib.sha256(" ".join(knobs).encode()).hexdigest()[:10])
+    sid = source_id() + ("+" + "+".join(k.lstrip("-D") for k in knobs) if knobs else "") + ("+instr" if instrument else "")
+    flags.append('-DRSRT_BUILD_ID="%s"' % sid)
     with _locked():
         if force or _newer(target, _deps("hip")):
             tmp = target + ".tmp%d" % os.getpid()

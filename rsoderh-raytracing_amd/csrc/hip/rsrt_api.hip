@@ -299,38 +299,42 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_resolve_kernel(RenderParams P, fl
     accum[(size_t)py * P.width + px] = a;
 }
 
+// The ray-query probe.  SV / TRAV as in rt_render_pool_kernel (where the scene is read from, which traversal
+// runs); TRAV == 3 is the first kernel's stack walk.  mode bit 0: cast_ray_bvh only (no brute-force fallback).
+template <int SV, int TRAV>
 __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uint32_t n, const float *origins, const float *dirs,
                                                                 uint32_t mode, uint32_t flags, rsrt_hit *out)
 {
-    const SceneView<false> S = make_view<false>(sc);
-    uint32_t *stack = reinterpret_cast<uint32_t *>(rt_smem) + threadIdx.x;
+    if (SV != 0) stage_scene_lds(sc);
+    const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
+    uint32_t *stack = reinterpret_cast<uint32_t *>(rt_smem + sc.lds_float4s) + threadIdx.x;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     V3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
     V3 d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
     const bool prune = (flags & RSRT_FLAG_PRUNE) != 0;
     Hit h;
-    if (mode & 2u) { // the stack traversal of the first kernel
-        if ((mode & 1u) == 0) trace_closest(S, sc, o, d, prune, stack, RT_BLOCK, h);
-        else trace_bvh<false>(S, o, d, prune, stack, RT_BLOCK, h);
-    } else { // the threaded traversal of the production kernel
-        uint32_t cur = 0;
-        h.t = RT_INFINITY; h.ref = 0; h.src = SRC_BVH; h.u = h.v = 0.0f;
+    h.t = RT_INFINITY; h.ref = 0; h.src = SRC_BVH; h.u = h.v = 0.0f;
+    if (TRAV == 3) { // the stack traversal of the first kernel
+        trace_bvh<false>(S, o, d, prune, stack, RT_BLOCK, h);
+    } else { // what the production kernel's TRACE stage runs, resumed until done as the scheduler would
 #ifdef RT_INSTRUMENT
         DbgCounters dbg;
 #endif
-        trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, false, 0xffffffffu, cur, h);
-        if ((mode & 1u) == 0 && !h.did_hit()) { // cast_ray's brute-force fallback
-            for (uint32_t k = 0; k < sc.n_spheres; k++) {
-                float u, v;
-                float t = test_record(S, k, SRC_FB_SPHERE, o, d, u, v);
-                if (t >= 0.0f && t < h.t) { h.t = t; h.ref = k; h.src = SRC_FB_SPHERE; }
-            }
-            for (uint32_t k = 0; k < sc.n_planes; k++) {
-                float u, v;
-                float t = test_record(S, k, SRC_FB_PLANE, o, d, u, v);
-                if (t >= 0.0f && t < h.t) { h.t = t; h.ref = k; h.src = SRC_FB_PLANE; }
-            }
+        uint32_t cur = 0;
+        while (cur != RT_END) trace_dispatch<(TRAV == 3 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, cur, h);
+        if (h.did_hit()) hit_barycentrics(S, h, o, d); // as SHADE does: the traversals do not carry u, v
+    }
+    if ((mode & 1u) == 0 && !h.did_hit()) { // cast_ray's brute-force fallback (the MISS stage)
+        for (uint32_t k = 0; k < sc.n_spheres; k++) {
+            float u, v;
+            float t = test_record(S, k, SRC_FB_SPHERE, o, d, u, v);
+            if (t >= 0.0f && t < h.t) { h.t = t; h.ref = k; h.src = SRC_FB_SPHERE; }
+        }
+        for (uint32_t k = 0; k < sc.n_planes; k++) {
+            float u, v;
+            float t = test_record(S, k, SRC_FB_PLANE, o, d, u, v);
+            if (t >= 0.0f && t < h.t) { h.t = t; h.ref = k; h.src = SRC_FB_PLANE; }
         }
     }
     rsrt_hit r;
@@ -405,6 +409,21 @@ static const void *variant_function(int kv, int sv, int trav)
     return sv == 1 ? pool_function<1, RT_BLOCK, 160>(trav) : pool_function<0, RT_BLOCK, 160>(trav);
 }
 
+template <int SV>
+static const void *probe_function_sv(int trav)
+{
+    switch (trav) {
+    case 0: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 0>);
+    case 1: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 1>);
+    case 2: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, (SV == 2 ? 1 : 2)>); // (flat needs the whole image: never asked for with SV 2)
+    default: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 3>);
+    }
+}
+static const void *probe_function(int sv, int trav)
+{
+    return sv == 0 ? probe_function_sv<0>(trav) : (sv == 1 ? probe_function_sv<1>(trav) : probe_function_sv<2>(trav));
+}
+
 struct rsrt_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -439,6 +458,15 @@ struct rsrt_context {
     unsigned long long base_counts[3] = {0, 0, 0};
     uint32_t cum_launches = 0, base_launches = 0;
     std::vector<hipEvent_t> event_pool;
+    // Work buffers (work_counter, sample_buf, cold_state, scratch) and the accumulator are per-context
+    // singletons, so everything the context enqueues is ONE chain whatever streams the caller passes:
+    // `last_event` is recorded after every enqueue, and an enqueue on a different stream first waits for it.
+    hipEvent_t last_event = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool last_valid = false;
+    // scratch for rsrt_resolve_mean_f16 / rsrt_display_srgb8 (grow-only; no per-frame hipMalloc)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
     int blocks_per_cu[9][RT_N_VARIANTS] = {}; // [scene view * 3 + traversal][kernel variant]
     int kernel_variant = 2; // index into kVariantPool
     int max_traversal = 2; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
@@ -533,6 +561,38 @@ rsrt_status ensure_accumulator(rsrt_context *ctx, uint32_t w, uint32_t h)
     return RSRT_OK;
 }
 
+// Orders `stream` after everything this context has enqueued so far (no-op on the same stream).
+rsrt_status begin_work(rsrt_context *ctx, hipStream_t stream)
+{
+    if (ctx->last_valid && ctx->last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->last_event, 0));
+    return RSRT_OK;
+}
+// Marks the end of what was just enqueued on `stream`.
+rsrt_status end_work(rsrt_context *ctx, hipStream_t stream)
+{
+    HIP_TRY(ctx, hipEventRecord(ctx->last_event, stream));
+    ctx->last_stream = stream;
+    ctx->last_valid = true;
+    return RSRT_OK;
+}
+// Waits for everything the context has enqueued, on whatever stream.
+rsrt_status sync_all(rsrt_context *ctx)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->last_valid) HIP_TRY(ctx, hipEventSynchronize(ctx->last_event));
+    return RSRT_OK;
+}
+rsrt_status ensure_scratch(rsrt_context *ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_bytes) return RSRT_OK;
+    rsrt_status st = sync_all(ctx);
+    if (st) return st;
+    if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    HIP_TRY(ctx, hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return RSRT_OK;
+}
+
 hipEvent_t get_event(rsrt_context *ctx)
 {
     if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
@@ -546,7 +606,7 @@ hipEvent_t get_event(rsrt_context *ctx)
 rsrt_status collect_events(rsrt_context *ctx)
 {
     if (ctx->pending_events.empty()) return RSRT_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     for (auto &pe : ctx->pending_events) {
         float t1 = 0, t2 = 0;
         HIP_TRY(ctx, hipEventSynchronize(pe.end));
@@ -565,8 +625,9 @@ rsrt_status collect_events(rsrt_context *ctx)
 // rsrt_get_stats: cumulative totals now, and the difference to the totals at the previous call.
 rsrt_status collect_stats(rsrt_context *ctx)
 {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    rsrt_status st = collect_events(ctx);
+    rsrt_status st = sync_all(ctx);
+    if (st) return st;
+    st = collect_events(ctx);
     if (st) return st;
     unsigned long long c[RT_STATS_WORDS] = {0}; // device counters are cumulative
     HIP_TRY(ctx, hipMemcpy(c, ctx->dev_stats, sizeof c, hipMemcpyDeviceToHost));
@@ -587,6 +648,56 @@ rsrt_status collect_stats(rsrt_context *ctx)
     ctx->base_resolve_ms = ctx->cum_resolve_ms;
     ctx->base_launches = ctx->cum_launches;
     memcpy(ctx->debug_words, c + 3, sizeof ctx->debug_words);
+    return RSRT_OK;
+}
+
+
+// One pass of rsrt_render: the path-tracing kernel over P.sample_count samples, then the ordered resolve.
+rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context::PassEvents &pe, const void *kfn, uint32_t block, int bpc,
+                         size_t smem, size_t per_sample, uint32_t max_bounces, hipStream_t stream)
+{
+    const uint32_t tile_px = P.tile_w * P.tile_h;
+    HIP_TRY(ctx, hipEventRecord(pe.begin, stream));
+    if (max_bounces > 0) {
+        // chunk = one tile x samples_per_chunk samples.  Up to 8 samples per chunk (2048 paths: the
+        // counter is touched rarely), fewer when the job is small — e.g. one GPU's share of a
+        // partitioned frame — so that every resident wave still gets >= ~32 chunks and the tail,
+        // where waves run out of work at different times, stays a few percent.
+        {
+            const uint64_t waves = (uint64_t)ctx->cus * bpc * (block / RT_WAVE);
+            const uint64_t want_chunks = 32ull * waves;
+            const uint64_t total_tile_samples = (uint64_t)P.n_owned_tiles * P.sample_count;
+            uint64_t spc = total_tile_samples / std::max<uint64_t>(want_chunks, 1);
+            spc = std::min<uint64_t>(std::max<uint64_t>(spc, 1), std::max<uint32_t>(1u, 2048u / tile_px));
+            P.samples_per_chunk = (uint32_t)std::min<uint64_t>(spc, P.sample_count);
+            // very small jobs (one sample per call, the reference's interactive mode): split tiles too,
+            // down to one wave's worth of pixels per chunk
+            P.n_subtiles = 1;
+            while (P.samples_per_chunk == 1 && total_tile_samples * P.n_subtiles < want_chunks && tile_px / (P.n_subtiles * 2) >= RT_WAVE &&
+                   tile_px % (P.n_subtiles * 2) == 0)
+                P.n_subtiles *= 2;
+            P.chunk_px = tile_px / P.n_subtiles;
+        }
+        P.n_sblocks = (P.sample_count + P.samples_per_chunk - 1) / P.samples_per_chunk;
+        const uint64_t n_chunks = (uint64_t)P.n_owned_tiles * P.n_sblocks * P.n_subtiles;
+        if (n_chunks > 0xffffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "too many work chunks");
+        P.n_chunks = (uint32_t)n_chunks;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, sizeof(unsigned int), stream));
+        const uint32_t waves_wanted = (uint32_t)std::min<uint64_t>(n_chunks, 0x7fffffffull);
+        const uint32_t wpb = block / RT_WAVE;
+        uint32_t grid = std::min<uint32_t>((waves_wanted + wpb - 1) / wpb, (uint32_t)(ctx->cus * bpc));
+        grid = std::max(grid, 1u);
+        void *kargs[] = {&P};
+        HIP_TRY(ctx, hipLaunchKernel(kfn, dim3(grid), dim3(block), kargs, smem, stream));
+        ctx->cum_launches++;
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->sample_buf, 0, per_sample * P.sample_count, stream));
+    }
+    HIP_TRY(ctx, hipEventRecord(pe.traced, stream));
+    hipLaunchKernelGGL(rt_resolve_kernel, dim3((P.n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, P, ctx->accum);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->cum_launches++;
+    HIP_TRY(ctx, hipEventRecord(pe.end, stream));
     return RSRT_OK;
 }
 
@@ -612,6 +723,7 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     ctx->cus = prop.multiProcessorCount;
     DeviceGuard g(device_index);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->last_event, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc(&ctx->work_counter, sizeof(unsigned int))) != hipSuccess ||
         (e = hipMalloc(&ctx->dev_stats, RT_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(ctx->dev_stats, 0, RT_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess) {
@@ -628,7 +740,7 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     if (const char *hy = getenv("RSRT_HYBRID")) ctx->allow_hybrid = atoi(hy) != 0; // 0: mid-size scenes read everything from global memory (A/B)
     if (const char *ty = getenv("RSRT_TRAVERSAL")) ctx->max_traversal = atoi(ty); // cap: 0 generic tree walk, 1 typed leaf loops, 2 flat small-scene loop (A/B)
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_cast_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int m = 0; m < 12; m++) (void)hipFuncSetAttribute(probe_function(m / 4, m % 4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
     snprintf(buf, sizeof buf, "librsrt 0.1; %s (%s); %d CUs", prop.name, prop.gcnArchName, ctx->cus);
     ctx->description = buf;
@@ -640,7 +752,9 @@ void rsrt_context_destroy(rsrt_context *ctx)
 {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)sync_all(ctx);
+    if (ctx->last_event) (void)hipEventDestroy(ctx->last_event);
+    (void)hipFree(ctx->scratch);
     for (auto &pe : ctx->pending_events) { (void)hipEventDestroy(pe.begin); (void)hipEventDestroy(pe.traced); (void)hipEventDestroy(pe.end); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->scene_blob);
@@ -655,6 +769,11 @@ void rsrt_context_destroy(rsrt_context *ctx)
 }
 
 const char *rsrt_last_error(const rsrt_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+#ifndef RSRT_BUILD_ID
+#define RSRT_BUILD_ID "unknown"
+#endif
+const char *rsrt_build_id(void) { return RSRT_BUILD_ID; }
 
 const char *rsrt_describe(rsrt_context *ctx) { return ctx ? ctx->description.c_str() : "librsrt 0.1"; }
 
@@ -714,6 +833,8 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
                 st.push_back({i + 1, d + 1});
             }
         }
+        for (uint32_t i = 0; i < n_nodes; i++) // (the tables built below are indexed by every node)
+            if (!seen[i]) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh node %u is not reachable from the root", i);
     }
     // ---- threaded traversal links: escape[octant][node] (rt_device.h, trace_threaded)
     std::vector<uint32_t> escape(8ull * n_nodes, RT_END);
@@ -737,7 +858,19 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     const size_t esc_f4 = (8ull * n_nodes + 3) / 4;
     // ---- flat small-scene traversal (rt_device.h, trace_flat): leaf list, record masks, per-octant visiting ranks
     std::vector<uint32_t> leaf_nodes;
-    bool flat_ok = n_primitives <= 64; // ... and few enough leaves that testing every leaf box beats the tree walk (checked below)
+    // ... at most 64 records of each kind (a hit is carried as a 6-bit record index + 2-bit source in the idle cursor
+    // bits), few enough leaves that testing every leaf box beats the tree walk, and (below) nested boxes and leaves
+    // that share no record: the rank table gives every record ONE position in the visiting order
+    bool flat_ok = n_primitives <= 64 && n_spheres <= 64 && n_planes <= 64;
+    {
+        std::vector<uint8_t> covered(n_primitives, 0);
+        for (uint32_t i = 0; i < n_nodes && flat_ok; i++)
+            for (uint32_t k = 0; k < nodes[i].primitives_len && flat_ok; k++) {
+                uint8_t &c = covered[nodes[i].primitives_or_second_child_index + k];
+                flat_ok = c == 0;
+                c = 1;
+            }
+    }
     for (uint32_t i = 0; i < n_nodes; i++) {
         const rsrt_bvh_node &nd = nodes[i];
         if (nd.primitives_len != 0) { leaf_nodes.push_back(i); continue; }
@@ -833,7 +966,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         memcpy(p, flat_rank.data(), flat_rank.size() * sizeof(uint32_t));
     }
 
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     if (ctx->scene_blob) { (void)hipFree(ctx->scene_blob); ctx->scene_blob = nullptr; }
     ctx->scene_ready = false;
     HIP_TRY(ctx, hipMalloc(&ctx->scene_blob, img.size() * sizeof(float4)));
@@ -881,7 +1014,7 @@ rsrt_status rsrt_upload_environment(rsrt_context *ctx, uint32_t slot, uint32_t w
         if (alias[i].alias_index >= n) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "alias entry %zu: alias_index %u out of range", i, alias[i].alias_index);
     if (ctx->envs.size() <= slot) ctx->envs.resize(slot + 1);
     Env &e = ctx->envs[slot];
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     if (e.rgba) { (void)hipFree(e.rgba); e.rgba = nullptr; }
     if (e.alias) { (void)hipFree(e.alias); e.alias = nullptr; }
     e.width = e.height = 0;
@@ -917,7 +1050,7 @@ rsrt_status rsrt_accumulator_bind(rsrt_context *ctx, void *device_rgba32f, uint3
 {
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
     DeviceGuard g(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     if (!device_rgba32f) {
         ctx->accum = ctx->accum_owned;
         if (!ctx->accum) ctx->acc_w = ctx->acc_h = 0;
@@ -937,8 +1070,10 @@ rsrt_status rsrt_accumulator_clear(rsrt_context *ctx)
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
     DeviceGuard g(ctx->device);
     if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
+    rsrt_status st = begin_work(ctx, ctx->stream);
+    if (st) return st;
     HIP_TRY(ctx, hipMemsetAsync(ctx->accum, 0, (size_t)ctx->acc_w * ctx->acc_h * sizeof(float4), ctx->stream));
-    return RSRT_OK;
+    return end_work(ctx, ctx->stream);
 }
 
 rsrt_status rsrt_accumulator_download(rsrt_context *ctx, float *host_rgba, size_t n_floats)
@@ -947,7 +1082,7 @@ rsrt_status rsrt_accumulator_download(rsrt_context *ctx, float *host_rgba, size_
     DeviceGuard g(ctx->device);
     if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
     if (!host_rgba || n_floats != (size_t)ctx->acc_w * ctx->acc_h * 4) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "download: expected %zu floats", (size_t)ctx->acc_w * ctx->acc_h * 4);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     HIP_TRY(ctx, hipMemcpy(host_rgba, ctx->accum, n_floats * sizeof(float), hipMemcpyDeviceToHost));
     return RSRT_OK;
 }
@@ -959,13 +1094,14 @@ rsrt_status rsrt_resolve_mean_f16(rsrt_context *ctx, uint32_t sample_total, uint
     if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
     const size_t n = (size_t)ctx->acc_w * ctx->acc_h;
     if (!host || n_halfs != n * 4 || sample_total == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "resolve_mean_f16: expected %zu halfs and sample_total > 0", n * 4);
-    ushort4 *tmp = nullptr;
-    HIP_TRY(ctx, hipMalloc(&tmp, n * sizeof(ushort4)));
+    rsrt_status st = ensure_scratch(ctx, n * sizeof(ushort4));
+    if (st || (st = begin_work(ctx, ctx->stream))) return st;
+    ushort4 *tmp = static_cast<ushort4 *>(ctx->scratch);
     hipLaunchKernelGGL(rt_mean_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->accum, n, 0.0f, sample_total, tmp);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(host, tmp, n * sizeof(ushort4), hipMemcpyDeviceToHost);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(ctx, RSRT_ERR_HIP, "resolve_mean_f16: %s", hipGetErrorString(e));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(host, tmp, n * sizeof(ushort4), hipMemcpyDeviceToHost, ctx->stream));
+    if ((st = end_work(ctx, ctx->stream))) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RSRT_OK;
 }
 
@@ -976,13 +1112,14 @@ rsrt_status rsrt_display_srgb8(rsrt_context *ctx, uint32_t sample_total, uint8_t
     if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
     const size_t n = (size_t)ctx->acc_w * ctx->acc_h;
     if (!host_rgba8 || n_bytes != n * 4 || sample_total == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "display_srgb8: expected %zu bytes and sample_total > 0", n * 4);
-    uchar4 *tmp = nullptr;
-    HIP_TRY(ctx, hipMalloc(&tmp, n * sizeof(uchar4)));
+    rsrt_status st = ensure_scratch(ctx, n * sizeof(uchar4));
+    if (st || (st = begin_work(ctx, ctx->stream))) return st;
+    uchar4 *tmp = static_cast<uchar4 *>(ctx->scratch);
     hipLaunchKernelGGL(rt_display_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->accum, n, sample_total, tmp);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(host_rgba8, tmp, n * sizeof(uchar4), hipMemcpyDeviceToHost);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(ctx, RSRT_ERR_HIP, "display_srgb8: %s", hipGetErrorString(e));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(host_rgba8, tmp, n * sizeof(uchar4), hipMemcpyDeviceToHost, ctx->stream));
+    if ((st = end_work(ctx, ctx->stream))) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RSRT_OK;
 }
 
@@ -1039,7 +1176,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     pass_samples = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(pass_samples, 0xffffffffull / P.n_slots)); // slot ids are 32-bit
     const size_t need = per_sample * pass_samples;
     if (need > ctx->sample_buf_bytes) {
-        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        if ((st = sync_all(ctx))) return st;
         if (ctx->sample_buf) { (void)hipFree(ctx->sample_buf); ctx->sample_buf = nullptr; ctx->sample_buf_bytes = 0; }
         HIP_TRY(ctx, hipMalloc(&ctx->sample_buf, need));
         ctx->sample_buf_bytes = need;
@@ -1069,75 +1206,36 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     if (kv != 0) { // cold path-state arena: one block of columns per wave that can be resident
         const size_t need_cold = (size_t)ctx->cus * bpc * (block / RT_WAVE) * C_COUNT * pool * sizeof(uint32_t);
         if (need_cold > ctx->cold_bytes) {
-            HIP_TRY(ctx, hipStreamSynchronize(stream));
+            if ((st = sync_all(ctx))) return st;
             if (ctx->cold_state) { (void)hipFree(ctx->cold_state); ctx->cold_state = nullptr; ctx->cold_bytes = 0; }
             HIP_TRY(ctx, hipMalloc(&ctx->cold_state, need_cold));
             ctx->cold_bytes = need_cold;
         }
         P.cold_state = ctx->cold_state;
     }
-    hipEvent_t last_end = nullptr;
+    // the context's buffers are shared by every call: order this stream after whatever ran last (another stream's
+    // render, rsrt_accumulator_clear on the context's own stream, ...)
+    if ((st = begin_work(ctx, stream))) return st;
     for (uint32_t done = 0; done < sample_count; done += pass_samples) {
-        rsrt_context::PassEvents pe = {get_event(ctx), get_event(ctx), get_event(ctx)};
-        HIP_TRY(ctx, hipEventRecord(pe.begin, stream));
         P.sample_begin = sample_begin + done;
         P.sample_count = std::min(pass_samples, sample_count - done);
-        if (max_bounces > 0) {
-            // chunk = one tile x samples_per_chunk samples.  Up to 8 samples per chunk (2048 paths: the
-            // counter is touched rarely), fewer when the job is small — e.g. one GPU's share of a
-            // partitioned frame — so that every resident wave still gets >= ~32 chunks and the tail,
-            // where waves run out of work at different times, stays a few percent.
-            {
-                const uint64_t waves = (uint64_t)ctx->cus * bpc * (block / RT_WAVE);
-                const uint64_t want_chunks = 32ull * waves;
-                const uint64_t total_tile_samples = (uint64_t)P.n_owned_tiles * P.sample_count;
-                uint64_t spc = total_tile_samples / std::max<uint64_t>(want_chunks, 1);
-                spc = std::min<uint64_t>(std::max<uint64_t>(spc, 1), std::max<uint32_t>(1u, 2048u / tile_px));
-                P.samples_per_chunk = (uint32_t)std::min<uint64_t>(spc, P.sample_count);
-                // very small jobs (one sample per call, the reference's interactive mode): split tiles too,
-                // down to one wave's worth of pixels per chunk
-                P.n_subtiles = 1;
-                while (P.samples_per_chunk == 1 && total_tile_samples * P.n_subtiles < want_chunks && tile_px / (P.n_subtiles * 2) >= RT_WAVE &&
-                       tile_px % (P.n_subtiles * 2) == 0)
-                    P.n_subtiles *= 2;
-                P.chunk_px = tile_px / P.n_subtiles;
-            }
-            P.n_sblocks = (P.sample_count + P.samples_per_chunk - 1) / P.samples_per_chunk;
-            const uint64_t n_chunks = (uint64_t)P.n_owned_tiles * P.n_sblocks * P.n_subtiles;
-            if (n_chunks > 0xffffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "too many work chunks");
-            P.n_chunks = (uint32_t)n_chunks;
-            HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, sizeof(unsigned int), stream));
-            const uint32_t waves_wanted = (uint32_t)std::min<uint64_t>(n_chunks, 0x7fffffffull);
-            const uint32_t wpb = block / RT_WAVE;
-            uint32_t grid = std::min<uint32_t>((waves_wanted + wpb - 1) / wpb, (uint32_t)(ctx->cus * bpc));
-            grid = std::max(grid, 1u);
-            void *kargs[] = {&P};
-            HIP_TRY(ctx, hipLaunchKernel(kfn, dim3(grid), dim3(block), kargs, smem, stream));
-            ctx->cum_launches++;
-        } else {
-            HIP_TRY(ctx, hipMemsetAsync(ctx->sample_buf, 0, per_sample * P.sample_count, stream));
+        rsrt_context::PassEvents pe = {get_event(ctx), get_event(ctx), get_event(ctx)};
+        const rsrt_status pst = enqueue_pass(ctx, P, pe, kfn, block, bpc, smem, per_sample, max_bounces, stream);
+        if (pst != RSRT_OK) { // nothing of this pass is pending: the three events go back to the pool
+            ctx->event_pool.push_back(pe.begin); ctx->event_pool.push_back(pe.traced); ctx->event_pool.push_back(pe.end);
+            (void)end_work(ctx, stream); // earlier passes may be in flight
+            return pst;
         }
-        HIP_TRY(ctx, hipEventRecord(pe.traced, stream));
-        hipLaunchKernelGGL(rt_resolve_kernel, dim3((P.n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, P, ctx->accum);
-        HIP_TRY(ctx, hipGetLastError());
-        ctx->cum_launches++;
-        HIP_TRY(ctx, hipEventRecord(pe.end, stream));
         ctx->pending_events.push_back(pe);
-        last_end = pe.end;
     }
-    if (stream != ctx->stream && last_end) {
-        // keep the context's own stream ordered after work submitted on the caller's stream
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, last_end, 0));
-    }
-    return RSRT_OK;
+    return end_work(ctx, stream);
 }
 
 rsrt_status rsrt_synchronize(rsrt_context *ctx)
 {
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
     DeviceGuard g(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return RSRT_OK;
+    return sync_all(ctx);
 }
 
 rsrt_status rsrt_get_stats(rsrt_context *ctx, rsrt_stats *out)
@@ -1178,6 +1276,7 @@ rsrt_status rsrt_selftest_numerics(rsrt_context *ctx, uint64_t out[4])
     if (!ctx || !out) return RSRT_ERR_INVALID_ARGUMENT;
     DeviceGuard g(ctx->device);
     unsigned long long *d = nullptr, h[4] = {0, 0, 0, ~0ull};
+    { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     HIP_TRY(ctx, hipMalloc(&d, sizeof h));
     hipError_t e = hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
@@ -1209,7 +1308,22 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
     DeviceGuard g(ctx->device);
     if (!ctx->scene_ready) return fail(ctx, RSRT_ERR_NOT_READY, "no scene uploaded");
     if (n == 0) return RSRT_OK;
-    if (!origins || !dirs || !out || mode > 3) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: bad arguments");
+    if (!origins || !dirs || !out || mode > 15) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: bad arguments");
+    // mode: bit 0 = cast_ray_bvh only; bits 1-2 = traversal (0 threaded, 1 stack, 2 typed leaf loops, 3 flat); bit 3 = scene
+    // read from LDS exactly as the production kernel stages it (whole image, or nodes + escape links for mid-size scenes)
+    DevScene sc = ctx->scene;
+    const uint32_t sel = (mode >> 1) & 3u;
+    const int trav = sel == 0 ? 0 : (sel == 1 ? 3 : (sel == 2 ? 1 : 2));
+    int sv = 0;
+    if (mode & 8u) {
+        if (sc.lds_float4s == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: this scene is not staged in LDS by the production kernel");
+        sv = sc.lds_hybrid ? 2 : 1;
+    } else {
+        sc.lds_float4s = 0;
+    }
+    if (trav == 1 && !sc.typed_leaves) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: typed leaf loops need leaves of at most 8 primitives");
+    if (trav == 2 && (!sc.flat_ok || sv == 2)) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: the flat traversal needs a scene of at most 64 records with nested boxes");
+    { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     float *d_o = nullptr, *d_d = nullptr;
     rsrt_hit *d_h = nullptr;
     hipError_t e = hipMalloc(&d_o, (size_t)n * 12);
@@ -1218,9 +1332,10 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
     if (e == hipSuccess) e = hipMemcpy(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_d, dirs, (size_t)n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        const size_t smem = (size_t)ctx->scene.stack_entries * RT_BLOCK * sizeof(uint32_t);
-        hipLaunchKernelGGL(rt_cast_rays_kernel, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), smem, ctx->stream, ctx->scene, n, d_o, d_d, mode, flags, d_h);
-        e = hipGetLastError();
+        const size_t smem = (size_t)sc.lds_float4s * sizeof(float4) + (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t);
+        if (smem > 160 * 1024) { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: needs %zu bytes of LDS", smem); }
+        void *kargs[] = {&sc, &n, &d_o, &d_d, &mode, &flags, &d_h};
+        e = hipLaunchKernel(probe_function(sv, trav), dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), kargs, smem, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d_h, (size_t)n * sizeof(rsrt_hit), hipMemcpyDeviceToHost);

@@ -1030,3 +1030,27 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
 #undef RT_FLAT_ACCEPT
 }
 
+// ------------------------------------------------------------------ which traversal runs
+// TRAV: 0 trace_threaded (any BVH), 1 trace_threaded_typed (no leaf longer than 8 primitives), 2 trace_flat (<= 64
+// records, nested boxes).  One function so that the production kernel's TRACE stage and the ray-query probe
+// (rsrt_cast_rays) run the very same code.  `cur` is the traversal cursor (0 = start at the root, RT_END = done),
+// `h` the best hit so far; the tree walks stop after ~`budget` steps and are resumed by calling again.
+template <int TRAV, class View>
+RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t &cur, Hit &h)
+{
+    if (TRAV == 2) {
+        const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+        // 0 * x is NaN exactly when x is infinite or NaN (an overflowing sum only sends a ray the long way round)
+        const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f;
+        if (finite == 0.0f) {
+            trace_flat(DBG_ARG S, sc, o, d, inv, anyhit, h);
+            cur = RT_END;
+        } else {
+            trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, 0xffffffffu, cur, h);
+        }
+    } else if (TRAV == 1) {
+        trace_threaded_typed(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, budget, cur, h);
+    } else {
+        trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, budget, cur, h);
+    }
+}

@@ -64,6 +64,18 @@ struct PoolLayout {
 
 RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE, MISS, SHADE, FINISH; IDLE -> ST_COUNT (none)
 
+// The lanes of a wave hand data to each other through memory: the compaction list, the hot columns and the stage tag
+// (LDS) and the cold columns (global memory) are written by the lane that runs a stage and read by whichever lane
+// picks the slot up next.  DS and VMEM operations of one wave execute in order, so nothing has to be waited for,
+// but the memory model still wants the hand-over spelled out: a wavefront-scope release / acquire pair around a
+// wave barrier.  It emits no instruction on gfx950; it keeps the compiler from moving or forwarding those accesses.
+#define RT_WAVE_HANDOVER()                                        \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    } while (0)
+
 #ifndef RT_POOL_WAVES_PER_SIMD
 #define RT_POOL_WAVES_PER_SIMD 4
 #endif
@@ -105,6 +117,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
 
     for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
         if (lane + 64u * k < POOL) SET_TAG(lane + 64u * k, TAG_FREE);
+    RT_WAVE_HANDOVER();
 
     uint32_t chunk_next = 0, chunk_left = 0, chunk_tile_slot0 = 0, chunk_tx0 = 0, chunk_ty0 = 0, chunk_s0 = 0, chunk_p0 = 0;
     bool exhausted = false;
@@ -145,6 +158,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             if (mine && pos < 64u) list[pos] = lane + 64u * k;
             base += (uint32_t)__popcll(m);
         }
+        RT_WAVE_HANDOVER(); // list[] is read by other lanes than wrote it
         const uint32_t n_run = min(best_n, 64u);
         const bool on = lane < n_run;
         const uint32_t slot = on ? list[lane] : 0u;
@@ -217,21 +231,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 h.src = SRC_BVH;
                 h.t = HOTF(H_T, slot); h.ref = 0; h.u = h.v = 0.0f; // ref of an earlier call stays in the cold column unless beaten
                 const float t_in = h.t;
-                if (TRAV == 2) {
-                    const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
-                    // 0 * x is NaN exactly when x is infinite or NaN (an overflowing sum only sends a ray the long way round)
-                    const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f;
-                    if (finite == 0.0f) {
-                        trace_flat(DBG_ARG S, sc, o, d, inv, shadow && anyhit_shadow, h);
-                        cur = RT_END;
-                    } else {
-                        trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, 0xffffffffu, cur, h);
-                    }
-                } else if (TRAV == 1) {
-                    trace_threaded_typed(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
-                } else {
-                    trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
-                }
+                trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
                 const bool done = cur == RT_END;
                 if (!done) { // to be resumed: best t and cursor
                     SETH(H_T, slot, h.t);
@@ -375,6 +375,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 SET_TAG(slot, TAG_FREE);
             }
         }
+        RT_WAVE_HANDOVER(); // tags, hot and cold columns: the next census / stage reads them from other lanes
         DBG_STAMP(16 + best); // the stage just run
     }
 #undef HOT

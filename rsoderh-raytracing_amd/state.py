@@ -23,11 +23,16 @@ _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "r
             "rsrt_upload_environment", "rsrt_set_partition", "rsrt_accumulator_resize", "rsrt_accumulator_bind",
             "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_render",
             "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters", "rsrt_display_srgb8",
-            "rsrt_selftest_numerics"]
+            "rsrt_selftest_numerics", "rsrt_build_id"]
 
 
 class RsrtError(RuntimeError):
     pass
+
+
+def build_id():
+    """rsrt_build_id(): which kernel sources the loaded librsrt.so was compiled from."""
+    return lib().rsrt_build_id().decode()
 
 
 class Stats(C.Structure):
@@ -59,6 +64,8 @@ def lib():
         L.rsrt_last_error.argtypes = [C.c_void_p]
         L.rsrt_describe.restype = C.c_char_p
         L.rsrt_describe.argtypes = [C.c_void_p]
+        L.rsrt_build_id.restype = C.c_char_p
+        L.rsrt_build_id.argtypes = []
         L.rsrt_context_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.rsrt_context_destroy.argtypes = [C.c_void_p]
         L.rsrt_upload_scene.argtypes = [C.c_void_p] + [C.c_void_p, C.c_uint32] * 8

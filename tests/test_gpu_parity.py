@@ -55,14 +55,34 @@ def test_matches_golden_images_bit_exact(name):
             assert [st["paths"], st["ext_rays"], st["shadow_rays"]] == list(g["rays_%dspp_%db" % (spp, mb)])
 
 
+def probe_modes(name):
+    """Every way rsrt_cast_rays can run a query (include/rsrt.h): traversal 0 threaded / 1 stack / 2 typed leaf loops /
+    3 flat (what house, default and cube run in production; suzanne's 968 triangles do not qualify), x scene read from
+    global memory or from LDS as the production kernel stages it (bit 3), x cast_ray / cast_ray_bvh (bit 0)."""
+    sels = [0, 1, 2] + ([3] if name != "suzanne" else [])
+    return [(sel << 1) | lds | bvh_only for sel in sels for lds in (0, 8) for bvh_only in (0, 1)]
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_ray_batch_matches_golden_bit_exact(name):
+    """The committed 1 k-ray hit records through all four traversals, the production ones included."""
     g = golden(name)
     st = R.State.new(R.Scene.load_toml(util.scene_path(name)), golden_env(), 16, 16)
-    for mode, key in [(0, "hits"), (1, "hits_bvh"), (2, "hits"), (3, "hits_bvh")]:
+    for mode in probe_modes(name):
+        key = "hits_bvh" if mode & 1 else "hits"
         for flags in (0, R.state.FLAG_REFERENCE_TRAVERSAL):
             h = st.cast_rays(g["ray_o"], g["ray_d"], mode, flags)
-            assert np.array_equal(np.ascontiguousarray(h).view(np.uint32).reshape(-1, 9), g[key]), (key, flags)
+            assert np.array_equal(np.ascontiguousarray(h).view(np.uint32).reshape(-1, 9), g[key]), (key, mode, flags)
+    st.close()
+
+
+def test_probe_refuses_a_traversal_the_scene_does_not_qualify_for():
+    st = R.State.new(R.Scene.load_toml(util.scene_path("suzanne")), golden_env(), 16, 16)
+    o, d = np.zeros((4, 3), np.float32), np.tile(np.float32([0, 0, -1]), (4, 1))
+    with pytest.raises(R.RsrtError, match="flat traversal"):
+        st.cast_rays(o, d, 3 << 1, 0)
+    with pytest.raises(R.RsrtError, match="bad arguments"):
+        st.cast_rays(o, d, 16, 0)
     st.close()
 
 
@@ -133,7 +153,7 @@ def test_axis_parallel_rays_on_box_faces_bit_exact(name):
     osc = util.oracle_scene(sc)
     o, d = _axis_parallel_rays(sc, np.random.default_rng(11))
     st = R.State.new(sc, golden_env(), 16, 16)
-    for mode in (0, 1, 2, 3):  # threaded traversal (production kernel), then the stack traversal
+    for mode in probe_modes(name):  # all four traversals (flat: these rays take its tree-walk fallback), LDS and global
         ref = oracle.cast_rays(osc, o, d, mode & 1, 0)
         got = st.cast_rays(o, d, mode, 0)
         a = np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9)
@@ -214,6 +234,27 @@ def test_sample_ranges_compose_exactly(big_env):
     st.close()
     assert np.array_equal(util.bits(one), util.bits(two))
     assert np.array_equal(util.bits(one), util.bits(prog))
+
+
+def test_renders_on_different_caller_streams_are_one_chain(big_env):
+    """rsrt_accumulator_clear runs on the context's own stream; renders may be put on any caller stream.  The work
+    buffers and the accumulator belong to the context, so the library orders every enqueue after the previous one,
+    whatever the stream: clear -> render on s1 -> render on s2 -> render on the context's stream == one render."""
+    import torch
+    sc = R.Scene.load_toml(util.scene_path("house"))
+    w, h = 320, 180  # big enough that a render is still running when the next one is enqueued
+    ref, _ = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), w, h, 0, 7, 8)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    st = R.State.new(sc, big_env, w, h)
+    st.max_bounces = 8
+    for _ in range(3):  # the second and third round clear an accumulator that is full of samples
+        st._last_hash = None
+        st.render_samples(3, stream=s1.cuda_stream)   # hash changed: clear (context stream), then samples 0..2 on s1
+        st.render_samples(2, stream=s2.cuda_stream)   # samples 3..4 on another stream, same sample buffer / path arena
+        st.render_samples(2)                          # samples 5..6 on the context's own stream
+        img = st.download()
+        assert np.array_equal(util.bits(img), util.bits(ref))
+    st.close()
 
 
 def test_sample_buffer_passes_do_not_change_the_image(big_env, monkeypatch):
@@ -417,6 +458,41 @@ def test_bvh_whose_boxes_do_not_nest_keeps_the_tree_walk(big_env):
     img, st = gpu_render(sc, big_env, 96, 64, 0, 4, 10)
     assert np.array_equal(util.bits(img), util.bits(ref))
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+
+
+def test_leaves_that_share_records_or_too_many_fallback_records_keep_the_tree_walk(big_env):
+    """The flat loop carries a hit as a 6-bit record index and gives every record ONE visiting rank.  A foreign BVH
+    whose leaves overlap (a record in two leaves: the reference simply tests it twice), or a scene with more than 64
+    spheres behind a 64-record BVH, must fall back to the tree walk and still match the oracle."""
+    from rsoderh_raytracing_amd import types as T
+    base = R.Scene.load_toml(util.scene_path("default"))
+    nodes = base.bvh_nodes.copy()
+    leaves = [i for i in range(len(nodes)) if nodes[i]["primitives_len"] > 1]
+    b_ = next(i for i in leaves[1:] if nodes[i]["primitives_or_second_child_index"] > 0)
+    nodes[b_]["primitives_or_second_child_index"] -= 1  # leaf b now also holds its left neighbour's last record ...
+    nodes[b_]["primitives_len"] += 1                    # (boxes untouched: they still nest, only the sharing disqualifies)
+    sc = R.Scene(base.materials, base.spheres, base.plane_descs, base.vertices, base.normals, base.triangles, base.camera_desc,
+                 planes=base.planes, primitives=base.primitives, bvh_nodes=nodes, bvh_depth=base.bvh_depth)
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 96, 64, 0, 4, 10)
+    img, st = gpu_render(sc, big_env, 96, 64, 0, 4, 10)
+    assert np.array_equal(util.bits(img), util.bits(ref))
+    assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+    # 70 spheres, of which the BVH (and so `primitives`) knows only the first 10: cast_ray's brute-force loop still
+    # visits all 70 after a BVH miss (shader.wgsl:583-590), and a hit on sphere 64.. does not fit 6 bits
+    spheres = np.zeros(70, T.SPHERE)
+    spheres[:10] = base.spheres
+    for i in range(10, 70):
+        spheres[i]["pos"] = (-6.0 + 0.2 * i, 2.5 + 0.03 * i, -4.0)
+        spheres[i]["radius"] = 0.12
+        spheres[i]["material_id"] = i % len(base.materials)
+    sc2 = R.Scene(base.materials, spheres, base.plane_descs, base.vertices, base.normals, base.triangles, base.camera_desc,
+                  planes=base.planes, primitives=base.primitives, bvh_nodes=base.bvh_nodes, bvh_depth=base.bvh_depth)
+    ref2, ost2 = oracle.render(util.oracle_scene(sc2), util.oracle_env(big_env), sc2.camera_uniform().view(oracle.CAMERA), 96, 64, 0, 4, 10)
+    plain, _ = oracle.render(util.oracle_scene(base), util.oracle_env(big_env), base.camera_uniform().view(oracle.CAMERA), 96, 64, 0, 4, 10)
+    assert not np.array_equal(util.bits(ref2), util.bits(plain))  # the extra spheres are seen (through the fallback only)
+    img2, st2 = gpu_render(sc2, big_env, 96, 64, 0, 4, 10)
+    assert np.array_equal(util.bits(img2), util.bits(ref2))
+    assert (st2["ext_rays"], st2["shadow_rays"]) == (ost2["ext_rays"], ost2["shadow_rays"])
 
 
 @pytest.mark.parametrize("traversal", ["2", "1", "0"])
