@@ -7,28 +7,52 @@ Workload (config.workload): assets house.toml, 1920x1080, 256 spp, 8 bounces, sy
 environment (the reference's HDRIs are missing blobs) — BASELINE.json configs[3], the
 configuration `metric` is quoted on.  A step = one complete frame (all 256 samples of every
 pixel) of that workload through the C-ABI, inputs resident in HBM.  With N GPUs the SAME frame is
-partitioned by interleaved 16x16 tiles (one process per GPU) and one RCCL reduce(sum) brings the
-accumulators to rank 0 inside the timed region ("scaling": "strong").
+partitioned by interleaved 16x16 tiles (one process per GPU) and ONE RCCL reduce(sum) of the accumulators —
+issued by librsrt itself (rsrt_comm_reduce, include/rsrt.h) — brings the frame to rank 0 inside the
+timed region ("scaling": "strong").  torch.distributed (gloo) is only the control plane: barrier,
+hand-over of the RCCL id, sums of the counters.
 
 metric = Mrays/s = (extension rays + issued shadow rays, counted on the device) / wall time;
-ms_per_step = ms/frame.  roofline + cpu_baseline as the round contract asks.
+ms_per_step = ms/frame.
+
+roofline: the kernel's scene is LDS-resident and its environment MALL-resident, so HBM is not the
+roof it is under; FP32 VALU issue is.  `frac` = useful f32 lane-instructions per SIMD-cycle / 32 (a SIMD retires
+at most one wave64 VALU instruction per 2 cycles = 32 lanes per cycle), from rocprofv3 PMC counters collected
+LIVE by this run: before the GPU is touched, rank 0 (N = 1) starts `rocprofv3 --kernel-trace --pmc ... -- python3
+bench.py --pmc-child` three times (separate passes: SQ + GRBM, FETCH_SIZE + LDS, WRITE_SIZE + TCC), each rendering
+one frame of the same workload with the same library.  If rocprofv3 cannot run, the committed counters of
+profiles/pmc_house_1080p_8b.json are used — but only when they were taken on the same kernel sources
+(rsrt_build_id); otherwise the object says so and carries no fraction.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-COUNTS_FILE = os.path.join(ROOT, "profiles", "algo_counts_house_1080p_8b.json")
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic_house_1080p_8b.json")  # rocprofv3 PMC, tools/profile.sh
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_SIMD = 256 * 4        # 256 CUs x 4 SIMD32
+LANES_PER_SIMD_CYCLE = 32.0  # wave64 VALU instruction = 2 cycles on a SIMD32 (guide: v_fma_f32 2 cyc)
+MAX_CLOCK_HZ = 2.4e9
+LDS_ARRAY_CYCLES_PER_CU_CYCLE = 1.0
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_house_1080p_8b.json")
+PMC_PASSES = [
+    ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+     "SQ_BUSY_CYCLES", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"],
+    ["FETCH_SIZE", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+     "SQ_WAVES"],
+    ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
+]
 
 
 def algorithmic_bytes(st):
@@ -42,37 +66,6 @@ def algorithmic_bytes(st):
     return b
 
 
-def cpu_leg(scene, env, width, height, bounces, log):
-    """cpu_baseline leg (rank 0, N = 1 only): the oracle port on the host cores, bounded sample."""
-    import oracle
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import util
-    osc, oenv, cam = util.oracle_scene(scene), util.oracle_env(env), scene.camera_uniform().view(oracle.CAMERA)
-    cores = os.cpu_count() or 1
-    # counts for the roofline: the traversal the kernel executes — every node the reference visits for
-    # extension rays, any-hit exit for shadow rays (pruning is not exactly result-preserving, DESIGN.md)
-    t = time.time()
-    _, counts = oracle.render(osc, oenv, cam, width, height, 0, 1, bounces, flags=oracle.FLAG_ANYHIT_SHADOW,
-                              n_threads=cores, fast=True)
-    t_counts = time.time() - t
-    # timed baseline: the reference's own traversal, sized for roughly 15 s (calibrated on 2 spp)
-    t = time.time()
-    oracle.render(osc, oenv, cam, width, height, 0, 2, bounces, flags=0, n_threads=cores, fast=True)
-    t_cal = (time.time() - t) / 2
-    spp = int(max(2, min(256, round(20.0 / max(t_cal, 0.01)))))
-    t = time.time()
-    _, st = oracle.render(osc, oenv, cam, width, height, 0, spp, bounces, flags=0, n_threads=cores, fast=True)
-    dt = time.time() - t
-    rays = st["ext_rays"] + st["shadow_rays"]
-    log("cpu_baseline: %d spp in %.2f s on %d threads = %.2f Mrays/s (counting pass 1 spp: %.2f s)" % (spp, dt, cores, rays / dt / 1e6, t_counts))
-    per_path = algorithmic_bytes(counts) / counts["paths"]
-    base = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "house.toml %dx%d, samples 0..%d of every pixel, %d bounces, reference traversal, liboracle_fast.so (-O3, OpenMP dynamic 16x16 tiles)"
-                      % (width, height, spp - 1, bounces),
-            "ms_per_frame_extrapolated": dt / spp * 256 * 1e3, "cpu_model": cpu_model(), "seconds": dt}
-    return base, per_path, counts
-
-
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -82,6 +75,185 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def cpu_leg(scene, env, width, height, bounces, log):
+    """cpu_baseline leg (rank 0, N = 1 only): the oracle port on the host cores, bounded sample.  BASELINE.md §2:
+    config 1 (default.toml 256x256, 4 spp, 3 bounces) timed in full; the bench workload on >= 4 spp, scaled."""
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    import rsoderh_raytracing_amd as R
+    osc, oenv, cam = util.oracle_scene(scene), util.oracle_env(env), scene.camera_uniform().view(oracle.CAMERA)
+    cores = os.cpu_count() or 1
+    # counts for the algorithmic-byte model: the traversal the kernel executes — every node the reference visits for
+    # extension rays, any-hit exit for shadow rays (pruning is not exactly result-preserving, DESIGN.md §2)
+    t = time.time()
+    _, counts = oracle.render(osc, oenv, cam, width, height, 0, 1, bounces, flags=oracle.FLAG_ANYHIT_SHADOW,
+                              n_threads=cores, fast=True)
+    t_counts = time.time() - t
+    # timed baseline: the reference's own traversal, sized for roughly 15-20 s (calibrated on 2 spp)
+    t = time.time()
+    oracle.render(osc, oenv, cam, width, height, 0, 2, bounces, flags=0, n_threads=cores, fast=True)
+    t_cal = (time.time() - t) / 2
+    spp = int(max(4, min(256, round(20.0 / max(t_cal, 0.01)))))
+    t = time.time()
+    _, st = oracle.render(osc, oenv, cam, width, height, 0, spp, bounces, flags=0, n_threads=cores, fast=True)
+    dt = time.time() - t
+    rays = st["ext_rays"] + st["shadow_rays"]
+    # config 1, complete, best of 3 (it takes milliseconds)
+    d_sc = R.Scene.load_toml(os.path.join(ROOT, "tests", "golden", "assets", "scenes", "default.toml"))
+    d_osc, d_cam = util.oracle_scene(d_sc), d_sc.camera_uniform().view(oracle.CAMERA)
+    best, c1 = None, None
+    for _ in range(3):
+        t = time.time()
+        _, c1 = oracle.render(d_osc, oenv, d_cam, 256, 256, 0, 4, 3, flags=0, n_threads=cores, fast=True)
+        best = min(best, time.time() - t) if best else time.time() - t
+    c1_rays = c1["ext_rays"] + c1["shadow_rays"]
+    # one core alone, for the per-core figure (threads do not scale linearly across sockets / SMT)
+    t = time.time()
+    _, s1 = oracle.render(osc, oenv, cam, width // 4, height // 4, 0, 1, bounces, flags=0, n_threads=1, fast=True)
+    dt1 = time.time() - t
+    log("cpu_baseline: %d spp in %.2f s on %d threads = %.2f Mrays/s (%.3f per thread; one thread alone %.3f); config 1 in %.1f ms; counting pass %.2f s"
+        % (spp, dt, cores, rays / dt / 1e6, rays / dt / 1e6 / cores, (s1["ext_rays"] + s1["shadow_rays"]) / dt1 / 1e6, best * 1e3, t_counts))
+    per_path = algorithmic_bytes(counts) / counts["paths"]
+    base = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "house.toml %dx%d, samples 0..%d of every pixel, %d bounces, reference traversal, liboracle_fast.so (-O3, OpenMP dynamic 16x16 tiles)"
+                      % (width, height, spp - 1, bounces),
+            "per_core_mrays_s": rays / dt / 1e6 / cores,
+            "single_thread_mrays_s": (s1["ext_rays"] + s1["shadow_rays"]) / dt1 / 1e6,
+            "ms_per_frame_extrapolated": dt / spp * 256 * 1e3, "extrapolation_factor": 256.0 / spp,
+            "config1_default_256x256_4spp_3b": {"ms": best * 1e3, "mrays_s": c1_rays / best / 1e6, "rays": c1_rays, "timed": "in full, best of 3"},
+            "cpu_model": cpu_model(), "seconds": dt}
+    return base, per_path, counts
+
+
+# ---------------------------------------------------------------------------------------------- PMC (rocprofv3)
+def pmc_child(args):
+    """Runs under rocprofv3: ONE frame of the workload through the C-ABI, nothing else (no torch)."""
+    import rsoderh_raytracing_amd as R
+    from rsoderh_raytracing_amd import state as S
+    scene = R.Scene.load_toml(os.path.join(ROOT, "tests", "golden", "assets", "scenes", args.scene + ".toml"))
+    env = R.Environment.synthetic(2048, 1024)
+    st = R.State.new(scene, env, args.width, args.height, device=0)
+    st.max_bounces = args.bounces
+    st.render_range(0, args.spp)
+    st.synchronize()
+    s = st.stats()
+    st.close()
+    print(json.dumps({"build_id": S.build_id(), "trace_kernel_ms": s["trace_kernel_ms"], "paths": s["paths"]}), flush=True)
+
+
+def collect_pmc(args, log):
+    """Three rocprofv3 --pmc passes of the child.  Returns {"counters": {...}, "kernel": name, "build_id": ..} or None."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        log("pmc: rocprofv3 not found")
+        return None
+    out = {"counters": {}, "resolve": {}, "kernel": None, "build_id": None, "launch_ms_under_pmc": None}
+    tmp = tempfile.mkdtemp(prefix="rsrt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for i, counters in enumerate(PMC_PASSES):
+            d = os.path.join(tmp, "pass%d" % i)
+            cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                                                                 "--pmc-child", "--scene", args.scene, "--width", str(args.width), "--height", str(args.height),
+                                                                 "--spp", str(args.spp), "--bounces", str(args.bounces)]
+            t = time.time()
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            if r.returncode != 0:
+                log("pmc pass %d failed (rc %d): %s" % (i, r.returncode, (r.stderr or r.stdout)[-400:]))
+                return None
+            child = None
+            for line in r.stdout.splitlines():
+                if line.startswith("{") and "build_id" in line:
+                    child = json.loads(line)
+            if child is None:
+                log("pmc pass %d: child printed no result line" % i)
+                return None
+            out["build_id"] = child["build_id"]
+            rows = 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        name = row["Kernel_Name"]
+                        if "rt_render_pool_kernel" in name or "rt_render_kernel" in name:
+                            out["kernel"] = name
+                            out["counters"][row["Counter_Name"]] = out["counters"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                            out["launch_ms_under_pmc"] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+                            rows += 1
+                        elif "rt_resolve_kernel" in name:
+                            out["resolve"][row["Counter_Name"]] = out["resolve"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            if rows == 0:
+                log("pmc pass %d: no counter rows for the render kernel" % i)
+                return None
+            log("pmc pass %d (%s ...): %.1f s" % (i, counters[0], time.time() - t))
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+        log("pmc: %r" % (e,))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["source"] = "live: rocprofv3 --kernel-trace --pmc, %d separate passes of one frame each, started by this bench run" % len(PMC_PASSES)
+    return out
+
+
+def roofline_object(pmc, build_id, launch_ms, paths_per_launch, per_path, owned_pixels, spp):
+    """The roofline of the dominant kernel.  pmc: collect_pmc()'s result (or the committed one) or None."""
+    algo = None
+    if per_path is not None:
+        algo_bytes = per_path * paths_per_launch + 16.0 * owned_pixels
+        algo = {"bytes_per_launch": algo_bytes, "bytes_per_path": per_path, "GB_per_s": algo_bytes / (launch_ms * 1e-3) / 1e9,
+                "frac_of_hbm_peak": algo_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "counts": "SURVEY §8(d) per-unit bytes x counts of the instrumented oracle on sample 0 of every pixel, UNPRUNED extension rays "
+                          "(t-pruning changes 2 of 5.3e8 paths, DESIGN.md §2: the kernel tests what the reference tests) + any-hit shadow rays",
+                "note": "these bytes are served by LDS (scene) and L2 / Infinity Cache (environment): a fraction of the HBM peak above 1 "
+                        "means HBM is not the roof"}
+    ro = {"bound": "valu", "achieved": None, "peak": LANES_PER_SIMD_CYCLE, "unit": "f32 lane-instructions per SIMD-cycle", "frac": None,
+          "traffic": None, "kernel": None, "build_id": build_id, "launch_ms": launch_ms, "sample_buffer_bytes_per_launch": 12.0 * paths_per_launch,
+          "algorithmic": algo}
+    if pmc is None:
+        ro["note"] = "no PMC counters: rocprofv3 could not run here and no committed profile matches this library's build id"
+        return ro
+    c = pmc["counters"]
+    cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs (guide: DVFS give-back)
+    insts = c["SQ_INSTS_VALU"]
+    lanes = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]  # lanes active per VALU instruction (both in quad-cycles)
+    ipc = insts / (cycles * N_SIMD)
+    ro.update({"achieved": ipc * lanes, "frac": ipc * lanes / LANES_PER_SIMD_CYCLE, "kernel": pmc["kernel"],
+               "counters": {k: c[k] for k in sorted(c)}, "counters_source": pmc["source"], "counters_build_id": pmc["build_id"],
+               "launch_ms_under_pmc": pmc.get("launch_ms_under_pmc"),
+               "valu": {"wave_instructions_per_launch": insts, "instructions_per_simd_cycle": ipc, "issue_peak_per_simd_cycle": 0.5,
+                        "issue_frac": ipc / 0.5, "lanes_active_per_instruction": lanes, "lane_frac": lanes / 64.0,
+                        "clock_ghz_under_pmc": cycles / (pmc["launch_ms_under_pmc"] * 1e-3) / 1e9 if pmc.get("launch_ms_under_pmc") else None,
+                        # the same work against the wall clock of THIS run's launches and the 2.4 GHz peak clock
+                        "wall": {"achieved_tera_lane_instructions_per_s": insts * lanes / (launch_ms * 1e-3) / 1e12,
+                                 "peak": N_SIMD * LANES_PER_SIMD_CYCLE * MAX_CLOCK_HZ / 1e12,
+                                 "frac": insts * lanes / (launch_ms * 1e-3) / (N_SIMD * LANES_PER_SIMD_CYCLE * MAX_CLOCK_HZ)},
+                        "wait_any_frac_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                        "wait_inst_any_frac_of_wave_cycles": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                        "salu_per_valu": c["SQ_INSTS_SALU"] / insts}})
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # FETCH_SIZE / WRITE_SIZE are KiB at the L2's fabric side (Infinity-Cache hits included).  gfx950 tallies a 128-byte
+        # read request as 64 bytes: the resolve kernel of the same pass streams a KNOWN byte count (12 B x paths) and
+        # calibrates the factor (2.0 on every run so far); the render kernel's reads are 128-byte lines too
+        # (tools/fetch_calib.hip, DESIGN.md §5), so the same factor applies.
+        known = 12.0 * paths_per_launch
+        r_fetch = pmc["resolve"].get("FETCH_SIZE", 0.0) * 1024.0
+        factor = known / r_fetch if r_fetch > 0 else 2.0
+        fetch, write = c["FETCH_SIZE"] * 1024.0 * factor, c["WRITE_SIZE"] * 1024.0
+        ro["traffic"] = fetch + write
+        ro["hbm"] = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "fetch_size_correction": factor,
+                     "correction_source": "rt_resolve_kernel of the same PMC pass: %.3e known bytes / %.3e counted" % (known, r_fetch),
+                     "GB_per_s": (fetch + write) / (launch_ms * 1e-3) / 1e9, "frac_of_hbm_peak": (fetch + write) / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "compulsory_bytes_per_launch": 12.0 * paths_per_launch + 2 * 2048 * 1024 * 16 + 16.0 * owned_pixels,
+                     "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0 else None}
+    if "SQ_LDS_IDX_ACTIVE" in c:
+        ro["lds"] = {"array_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / (cycles * 256 * LDS_ARRAY_CYCLES_PER_CU_CYCLE),
+                     "bank_conflict_frac_of_busy": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], "wave_instructions_per_launch": c["SQ_INSTS_LDS"],
+                     "note": "SQ_LDS_IDX_ACTIVE = LDS-array cycles summed over the 256 CUs; one array cycle moves up to 256 B"}
+    ro["note"] = ("bound = FP32 VALU issue: the scene (10 KB) is read from LDS and the 64 MiB environment from L2 / Infinity Cache, so neither HBM "
+                  "nor MFMA is the roof this kernel is under; frac = (VALU wave-instructions per SIMD-cycle) x (lanes active per instruction) / 32")
+    return ro
 
 
 def main():
@@ -95,9 +267,15 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--scene", default="house")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real thing) or gloo (rehearsal of N > 1 on one GPU)")
-    ap.add_argument("--write-counts", action="store_true", help="store the per-path algorithmic bytes under profiles/")
+    ap.add_argument("--no-pmc", action="store_true", help="do not start rocprofv3 (the committed counters are used if they match the library)")
+    ap.add_argument("--collective", default="rccl", choices=["rccl", "torch-nccl", "gloo"],
+                    help="rccl: rsrt_comm_reduce inside librsrt (the product path); torch-nccl: torch.distributed's reduce; "
+                         "gloo: host reduce (rehearsal of N > 1 on one GPU)")
+    ap.add_argument("--write-profile", action="store_true", help="store the PMC counters + algorithmic counts under profiles/")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,19 +289,24 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
+    std_cfg = (args.scene, args.width, args.height, args.bounces, args.spp) == ("house", 1920, 1080, 8, 256)
+    # PMC passes first: this process has not touched the GPU yet, the children come and go one at a time
+    pmc = None
+    if world == 1 and not args.no_pmc:
+        pmc = collect_pmc(args, log)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the integrator has no CPU path")
     device_index = local_rank % torch.cuda.device_count()  # == local_rank on a real N-GPU node
     torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)  # control plane only
 
     import rsoderh_raytracing_amd as R
-    from rsoderh_raytracing_amd import partition
+    from rsoderh_raytracing_amd import partition, state as S
     scene_file = os.path.join(ROOT, "tests", "golden", "assets", "scenes", args.scene + ".toml")
     scene = R.Scene.load_toml(scene_file)
     env = R.Environment.synthetic(2048, 1024)
@@ -135,14 +318,47 @@ def main():
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     state.bind_accumulator(acc.data_ptr(), W, H)
     stream = torch.cuda.Stream()
-    log(state.describe())
+    build_id = S.build_id()
+    log(state.describe() + "; build " + build_id)
+
+    # ---- the exchange step: RCCL inside librsrt; torch's own reduce only if that cannot be set up on every rank
+    collective, nccl_group = "none", None
+    if world > 1:
+        collective = args.collective
+        if collective == "rccl":
+            uid, err = [None], ""
+            if rank == 0:
+                try:
+                    uid[0] = R.State.comm_unique_id()
+                except R.RsrtError as e:
+                    err = str(e)
+            dist.broadcast_object_list(uid, src=0)
+            ok = torch.tensor([1 if uid[0] is not None else 0], dtype=torch.int32)
+            if uid[0] is not None:
+                try:
+                    state.comm_init(rank, world, uid[0])  # collective: every rank has the id, so every rank calls it
+                except R.RsrtError as e:
+                    ok[0], err = 0, str(e)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0:
+                log("rsrt_comm_init failed somewhere (%s): falling back to torch.distributed's nccl reduce" % err)
+                try:
+                    state.comm_destroy()
+                except R.RsrtError:
+                    pass
+                state.set_partition(rank, world, partition.TILE_W, partition.TILE_H)
+                collective = "torch-nccl"
+        if collective == "torch-nccl":
+            nccl_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", device_index))
 
     def step():
         acc.zero_()
         state.render_range(0, spp, stream=stream.cuda_stream)
         if world > 1:
-            if args.backend == "nccl":
-                partition.reduce_accumulators(acc)  # one RCCL reduce(sum) over xGMI
+            if collective == "rccl":
+                state.comm_reduce(0, stream=stream.cuda_stream)  # ONE ncclReduce(sum, f32) of W*H*4 floats over xGMI
+            elif collective == "torch-nccl":
+                partition.reduce_accumulators(acc, group=nccl_group)
             else:  # rehearsal: gloo reduces on the host
                 host = acc.cpu()
                 partition.reduce_accumulators(host)
@@ -150,6 +366,7 @@ def main():
                     acc.copy_(host)
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -162,18 +379,16 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        torch.cuda.synchronize()
         fence()
         elapsed = time.perf_counter() - t0
 
     s = state.stats()
-    cdev = "cuda" if args.backend == "nccl" else "cpu"
-    tot = torch.tensor([float(s["ext_rays"] + s["shadow_rays"]), float(s["paths"])], dtype=torch.float64, device=cdev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    tot = torch.tensor([float(s["ext_rays"] + s["shadow_rays"]), float(s["paths"])], dtype=torch.float64)
+    tmax = torch.tensor([elapsed, s["trace_kernel_ms"], s["reduce_ms"]], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    elapsed = float(tmax[0].item())
     rays_total, paths_total = float(tot[0].item()), float(tot[1].item())
 
     result = None
@@ -181,47 +396,48 @@ def main():
         frame = acc.cpu().numpy()
         assert np.isfinite(frame).all() and np.all(frame[..., 3] == 1.0), "frame incomplete"
         value = rays_total / elapsed / 1e6
-        launches_trace = args.steps * max(1, s["launches"] // (2 * args.steps))
+        launches_trace = args.steps * max(1, (s["launches"] // 2) // args.steps)
         trace_ms_per_launch = s["trace_kernel_ms"] / launches_trace
-        cpu_base, per_path = None, None
-        std_cfg = (args.scene, W, H, args.bounces) == ("house", 1920, 1080, 8)
+        cpu_base, per_path, counts = None, None, None
         if world == 1 and not args.no_cpu_baseline:
             cpu_base, per_path, counts = cpu_leg(scene, env, W, H, args.bounces, log)
-            if args.write_counts and std_cfg:
-                os.makedirs(os.path.dirname(COUNTS_FILE), exist_ok=True)
-                with open(COUNTS_FILE, "w") as f:
-                    json.dump({"per_path_algorithmic_bytes": per_path, "counts_1spp": counts,
-                               "source": "oracle, unpruned extension rays + any-hit shadow rays, sample 0 of every pixel"}, f, indent=1)
-        elif std_cfg and os.path.exists(COUNTS_FILE):
-            with open(COUNTS_FILE) as f:
-                per_path = json.load(f)["per_path_algorithmic_bytes"]
-        roofline = None
-        if per_path is not None:
-            paths_per_launch = s["paths"] / launches_trace  # this rank's kernel
-            owned_pixels = int(partition.owned_mask(W, H, rank, world).sum())
-            algo = per_path * paths_per_launch + 16.0 * owned_pixels
-            achieved = algo / (trace_ms_per_launch * 1e-3) / 1e9
-            traffic = issue = None  # PMC counters cannot be read from inside this process: committed rocprofv3 measurement
-            if std_cfg and world == 1 and spp == 256 and os.path.exists(TRAFFIC_FILE):
-                with open(TRAFFIC_FILE) as f:
-                    tj = json.load(f)
-                traffic = (tj.get("fetch_bytes_per_launch") or 0) + (tj.get("write_bytes_per_launch") or 0)
-                issue = tj.get("issue")  # what actually bounds the kernel: VALU issue (same rocprofv3 run)
-            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "kernel": "rt_render_pool_kernel", "launch_ms": trace_ms_per_launch,
-                        "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_per_path": per_path,
-                        "sample_buffer_bytes_per_launch": 24.0 * paths_per_launch, "valu_issue": issue,
-                        "note": "working set (10 KB scene image in LDS + 64 MiB environment, MALL-resident) is cache-resident by "
-                                "construction, so the fraction of the HBM peak exceeds 1; the kernel is bound by FP32 VALU issue "
-                                "and lane divergence (valu_issue, DESIGN.md section 5)"}
+        committed = None
+        if std_cfg and os.path.exists(PMC_FILE):
+            with open(PMC_FILE) as f:
+                committed = json.load(f)
+        if per_path is None and committed is not None:
+            per_path = committed.get("algorithmic_bytes_per_path")
+        if pmc is not None and pmc["build_id"] != build_id:
+            log("pmc: the child ran build %s, this process %s: counters dropped" % (pmc["build_id"], build_id))
+            pmc = None
+        if pmc is None and world == 1 and committed is not None:
+            if committed.get("build_id") == build_id:
+                pmc = {k: committed[k] for k in ("counters", "resolve", "kernel", "build_id", "launch_ms_under_pmc")}
+                pmc["source"] = "committed: profiles/pmc_house_1080p_8b.json (same rsrt_build_id as this library)"
+            else:
+                log("pmc: profiles/pmc_house_1080p_8b.json was taken on build %s, this library is %s: not attached" % (committed.get("build_id"), build_id))
+        paths_per_launch = s["paths"] / launches_trace  # this rank's kernel
+        owned_pixels = int(partition.owned_mask(W, H, rank, world).sum())
+        roofline = roofline_object(pmc if world == 1 else None, build_id, trace_ms_per_launch, paths_per_launch, per_path, owned_pixels, spp)
+        if world > 1:
+            roofline["note"] = "per-kernel counters are collected at N = 1 only; this object carries the launch time and the algorithmic bytes of rank 0's share"
+        if args.write_profile and std_cfg and world == 1 and pmc is not None and str(pmc.get("source", "")).startswith("live"):
+            os.makedirs(os.path.dirname(PMC_FILE), exist_ok=True)
+            with open(PMC_FILE, "w") as f:
+                json.dump({"workload": "house.toml 1920x1080 256 spp 8 bounces, one frame per PMC pass", "build_id": build_id, "kernel": pmc["kernel"],
+                           "launch_ms_under_pmc": pmc["launch_ms_under_pmc"], "counters": pmc["counters"], "resolve": pmc["resolve"],
+                           "algorithmic_bytes_per_path": per_path, "algorithmic_counts_1spp": counts,
+                           "passes": PMC_PASSES, "source": "bench.py --write-profile (rocprofv3 --kernel-trace --pmc, separate passes)"}, f, indent=1)
         result = {"metric": "Mrays/s, house.toml 1920x1080 256spp 8-bounce", "value": value, "unit": "Mrays/s",
                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                   "config": {"workload": "%s.toml %dx%d %d spp %d bounces, synthetic 2048x1024 HDRI env" % (args.scene, W, H, spp, args.bounces),
-                             "parallelism": "tiles16x16-interleaved x%d + rccl reduce" % world if world > 1 else "single GPU",
+                             "parallelism": ("tiles16x16-interleaved x%d, one reduce(sum) per frame via %s" % (world, {"rccl": "librsrt rsrt_comm_reduce (RCCL)", "torch-nccl": "torch.distributed nccl", "gloo": "gloo on the host (rehearsal)"}[collective]))
+                             if world > 1 else "single GPU",
                              "rays_per_frame": rays_total / args.steps, "paths_per_frame": paths_total / args.steps},
                   "ms_per_frame": elapsed / args.steps * 1e3,
-                  "kernel_ms_per_frame": {"trace": s["trace_kernel_ms"] / args.steps, "resolve": s["resolve_kernel_ms"] / args.steps},
+                  "kernel_ms_per_frame": {"trace": float(tmax[1].item()) / args.steps, "resolve": s["resolve_kernel_ms"] / args.steps,
+                                          "reduce": float(tmax[2].item()) / args.steps},
                   "roofline": roofline, "cpu_baseline": cpu_base}
     state.close()
     if world > 1:

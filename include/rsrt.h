@@ -45,7 +45,8 @@ typedef enum rsrt_status {
     RSRT_ERR_NO_DEVICE = 2,
     RSRT_ERR_HIP = 3,
     RSRT_ERR_NOT_READY = 4, /* scene or environment not uploaded / accumulator missing */
-    RSRT_ERR_OUT_OF_MEMORY = 5
+    RSRT_ERR_OUT_OF_MEMORY = 5,
+    RSRT_ERR_COMM = 6 /* RCCL missing or a collective failed (multi-GPU only) */
 } rsrt_status;
 
 typedef struct rsrt_context rsrt_context;
@@ -80,6 +81,7 @@ typedef struct rsrt_stats {
     uint32_t _pad;
     double trace_kernel_ms;   /* part of kernel_ms spent in the path-tracing kernel (rt_render_kernel) */
     double resolve_kernel_ms; /* part spent in the ordered sample resolve (rt_resolve_kernel) */
+    double reduce_ms;         /* HIP-event time of rsrt_comm_reduce calls (the RCCL reduce of the accumulators) */
 } rsrt_stats;
 
 /* -- context: State::new's device acquisition (state.rs:60-98) ------------------------------ */
@@ -115,6 +117,66 @@ rsrt_status rsrt_upload_environment(rsrt_context *ctx, uint32_t slot, uint32_t w
  * tile t iff t % world_size == rank and leaves every other pixel of the accumulator untouched.
  * Default: rank 0 of 1 (whole frame). */
 rsrt_status rsrt_set_partition(rsrt_context *ctx, uint32_t rank, uint32_t world_size, uint32_t tile_w, uint32_t tile_h);
+
+/* Pure host arithmetic of that partition (no GPU needed): the rank that renders pixel (x, y) (UINT32_MAX for bad
+ * arguments), and a width*height byte mask (1 = rendered by `rank`; mask may be NULL) with the pixel count. */
+uint32_t rsrt_partition_owner(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world_size, uint32_t x, uint32_t y);
+rsrt_status rsrt_partition_mask(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world_size,
+                                uint8_t *mask, uint64_t *owned_pixels);
+
+/* -- multi-GPU, form 1: one process (or thread) per GPU ----------------------------------------
+ * The one exchange step of the path — ONE reduce(sum, f32) of the W*H*4 accumulators per frame onto a root — runs on
+ * RCCL over xGMI INSIDE the library (librccl is dlopen'ed on first use; a single-GPU caller never needs it).  Every
+ * pixel has exactly one non-zero contributor, so the N-GPU frame equals the 1-GPU frame bit for bit.
+ *   rank 0:      rsrt_comm_unique_id(&id); hand the 128 bytes to the other ranks (file, socket, MPI, a torch store ...)
+ *   every rank:  rsrt_comm_init(ctx, rank, world, &id)   -- creates the communicator (collective call) and sets the tile
+ *                                                            partition (rank, world, current tile size)
+ *   per frame:   rsrt_accumulator_clear; rsrt_render ...; rsrt_comm_reduce(ctx, root, recv, stream)
+ * rsrt_comm_reduce is asynchronous on `hip_stream` (NULL = the context's stream) and ordered after the context's
+ * earlier work.  recv_device_rgba32f (root only, ignored elsewhere): where the full frame goes; NULL = in place, i.e.
+ * the root's accumulator becomes the full frame (clear it before rendering further samples); a progressive caller
+ * passes a separate W*H*4 f32 device buffer so that its accumulator keeps holding only its own tiles.
+ * Without rsrt_comm_init the world is one rank and the reduce is a (device) copy or nothing. */
+#define RSRT_UNIQUE_ID_BYTES 128
+typedef struct rsrt_unique_id { char bytes[RSRT_UNIQUE_ID_BYTES]; } rsrt_unique_id;
+rsrt_status rsrt_comm_unique_id(rsrt_unique_id *out); /* error text: rsrt_last_error(NULL) */
+rsrt_status rsrt_comm_init(rsrt_context *ctx, uint32_t rank, uint32_t world_size, const rsrt_unique_id *id);
+rsrt_status rsrt_comm_reduce(rsrt_context *ctx, uint32_t root, void *recv_device_rgba32f, void *hip_stream);
+rsrt_status rsrt_comm_destroy(rsrt_context *ctx); /* also done by rsrt_context_destroy */
+
+/* -- multi-GPU, form 2: one caller, a list of devices -----------------------
+ * What the reference's single-threaded `State` (src/state.rs:60-98 device acquisition, :760-833 render) would bind:
+ * one handle over 1/2/4/8 GPUs of the node.  Inside: one rsrt_context per device (rsrt_multi_context gives access,
+ * e.g. for per-device stats), ncclCommInitAll, device i renders tiles t % n == i, and the frame is reduced onto
+ * devices[0] (grouped ncclReduce into a frame buffer, so the per-device accumulators stay progressive) whenever
+ * it is asked for.  Calls mirror the single-device ones; errors: rsrt_multi_last_error (NULL handle: of the last
+ * failing rsrt_multi_create on this thread). */
+typedef struct rsrt_multi rsrt_multi;
+rsrt_status rsrt_multi_create(const int *devices, uint32_t n_devices, rsrt_multi **out);
+void rsrt_multi_destroy(rsrt_multi *m);
+const char *rsrt_multi_last_error(const rsrt_multi *m);
+uint32_t rsrt_multi_size(const rsrt_multi *m);
+rsrt_context *rsrt_multi_context(rsrt_multi *m, uint32_t i);
+rsrt_status rsrt_multi_upload_scene(rsrt_multi *m,
+                                    const rsrt_material *materials, uint32_t n_materials,
+                                    const rsrt_sphere *spheres, uint32_t n_spheres,
+                                    const rsrt_plane *planes, uint32_t n_planes,
+                                    const rsrt_vec3 *vertices, uint32_t n_vertices,
+                                    const rsrt_vec3 *normals, uint32_t n_normals,
+                                    const rsrt_triangle *triangles, uint32_t n_triangles,
+                                    const rsrt_primitive_info *primitives, uint32_t n_primitives,
+                                    const rsrt_bvh_node *bvh_nodes, uint32_t n_bvh_nodes);
+rsrt_status rsrt_multi_upload_environment(rsrt_multi *m, uint32_t slot, uint32_t width, uint32_t height,
+                                          const float *rgba, const rsrt_alias_entry *alias);
+rsrt_status rsrt_multi_resize(rsrt_multi *m, uint32_t width, uint32_t height);
+rsrt_status rsrt_multi_clear(rsrt_multi *m);
+rsrt_status rsrt_multi_render(rsrt_multi *m, const rsrt_camera *camera, uint32_t width, uint32_t height,
+                              uint32_t sample_begin, uint32_t sample_count, uint32_t max_bounces,
+                              uint32_t environment_index, uint32_t flags);
+rsrt_status rsrt_multi_synchronize(rsrt_multi *m);
+rsrt_status rsrt_multi_download(rsrt_multi *m, float *host_rgba, size_t n_floats);           /* reduce, then copy */
+rsrt_status rsrt_multi_display_srgb8(rsrt_multi *m, uint32_t sample_total, uint8_t *host_rgba8, size_t n_bytes);
+rsrt_status rsrt_multi_get_stats(rsrt_multi *m, rsrt_stats *out); /* counters summed, times = max over devices */
 
 /* -- accumulator: cumulative_light_texture (hdr.rs:217-223) ----------------------------------
  * Library-owned W*H RGBA32F sum on the device, (re)allocated and zeroed when the resolution

@@ -82,24 +82,30 @@ private:
 
 class State {
 public:
-    // State::new (src/state.rs:60-649)
-    State(const Scene &scene, const std::vector<const Environment *> &environments, uint32_t width, uint32_t height, int device = 0)
+    // State::new (src/state.rs:60-649) over a LIST of devices of one node (rsrt_multi_*): device i renders the tiles
+    // t % n == i, the frame is reduced onto devices[0] by RCCL inside librsrt whenever it is asked for.  {0} = one GPU.
+    State(const Scene &scene, const std::vector<const Environment *> &environments, uint32_t width, uint32_t height,
+          const std::vector<int> &devices = {0})
     {
-        if (rsrt_context_create(device, &ctx_) != RSRT_OK) throw Error(std::string("rsrt_context_create: ") + rsrt_last_error(nullptr));
-        const rsrt_scene *s = scene.handle();
-        const rsrt_scene_counts &c = scene.counts();
-        check(rsrt_upload_scene(ctx_, rsrt_scene_materials(s), c.n_materials, rsrt_scene_spheres(s), c.n_spheres, rsrt_scene_planes(s), c.n_planes,
-                                rsrt_scene_vertices(s), c.n_vertices, rsrt_scene_normals(s), c.n_normals, rsrt_scene_triangles(s), c.n_triangles,
-                                rsrt_scene_primitives(s), c.n_primitives, rsrt_scene_bvh_nodes(s), c.n_bvh_nodes),
-              "rsrt_upload_scene");
-        for (size_t i = 0; i < environments.size(); i++)
-            check(rsrt_upload_environment(ctx_, (uint32_t)i, environments[i]->width, environments[i]->height, environments[i]->rgba.data(),
-                                          environments[i]->alias.data()),
-                  "rsrt_upload_environment");
-        camera_ = scene.camera();
-        resize(width, height);
+        if (rsrt_multi_create(devices.data(), (uint32_t)devices.size(), &m_) != RSRT_OK) throw Error(rsrt_multi_last_error(nullptr));
+        try {
+            const rsrt_scene *s = scene.handle();
+            const rsrt_scene_counts &c = scene.counts();
+            check(rsrt_multi_upload_scene(m_, rsrt_scene_materials(s), c.n_materials, rsrt_scene_spheres(s), c.n_spheres, rsrt_scene_planes(s),
+                                          c.n_planes, rsrt_scene_vertices(s), c.n_vertices, rsrt_scene_normals(s), c.n_normals,
+                                          rsrt_scene_triangles(s), c.n_triangles, rsrt_scene_primitives(s), c.n_primitives, rsrt_scene_bvh_nodes(s),
+                                          c.n_bvh_nodes));
+            for (size_t i = 0; i < environments.size(); i++)
+                check(rsrt_multi_upload_environment(m_, (uint32_t)i, environments[i]->width, environments[i]->height, environments[i]->rgba.data(),
+                                                    environments[i]->alias.data()));
+            camera_ = scene.camera();
+            resize(width, height);
+        } catch (...) {
+            rsrt_multi_destroy(m_);
+            throw;
+        }
     }
-    ~State() { rsrt_context_destroy(ctx_); }
+    ~State() { rsrt_multi_destroy(m_); }
     State(const State &) = delete;
     State &operator=(const State &) = delete;
 
@@ -110,7 +116,7 @@ public:
     // State::resize (src/state.rs:651-666)
     void resize(uint32_t width, uint32_t height)
     {
-        check(rsrt_accumulator_resize(ctx_, width, height), "rsrt_accumulator_resize");
+        check(rsrt_multi_resize(m_, width, height));
         width_ = width; height_ = height;
         have_hash_ = false;
     }
@@ -118,6 +124,7 @@ public:
     void update(const rsrt_camera_desc &camera) { camera_ = camera; }
     const rsrt_camera_desc &camera() const { return camera_; }
     uint32_t sample_count() const { return sample_count_; }
+    uint32_t device_count() const { return rsrt_multi_size(m_); }
 
     // State::render (src/state.rs:760-833): one more sample per pixel; restart when the scene hash changed
     void render() { render_samples(1); }
@@ -126,38 +133,38 @@ public:
         const size_t h = scene_hash();
         if (!have_hash_ || h != last_hash_) { // src/state.rs:778-786
             last_hash_ = h; have_hash_ = true;
-            check(rsrt_accumulator_clear(ctx_), "rsrt_accumulator_clear");
+            check(rsrt_multi_clear(m_));
             sample_count_ = 0;
         }
         rsrt_camera cam;
         rsrt_camera_uniform(&camera_, &cam);
-        check(rsrt_render(ctx_, &cam, width_, height_, sample_count_, n, max_bounces, environment_index, flags, nullptr), "rsrt_render");
+        check(rsrt_multi_render(m_, &cam, width_, height_, sample_count_, n, max_bounces, environment_index, flags));
         sample_count_ += n;
     }
-    std::vector<float> download() // cumulative_light_texture
+    std::vector<float> download() // cumulative_light_texture, all devices' tiles
     {
         std::vector<float> out((size_t)width_ * height_ * 4);
-        check(rsrt_accumulator_download(ctx_, out.data(), out.size()), "rsrt_accumulator_download");
+        check(rsrt_multi_download(m_, out.data(), out.size()));
         return out;
     }
     std::vector<uint8_t> display() // what the window shows (hdr.wgsl + sRGB surface)
     {
         std::vector<uint8_t> out((size_t)width_ * height_ * 4);
-        check(rsrt_display_srgb8(ctx_, sample_count_, out.data(), out.size()), "rsrt_display_srgb8");
+        check(rsrt_multi_display_srgb8(m_, sample_count_, out.data(), out.size()));
         return out;
     }
     rsrt_stats stats()
     {
         rsrt_stats s;
-        check(rsrt_get_stats(ctx_, &s), "rsrt_get_stats");
+        check(rsrt_multi_get_stats(m_, &s));
         return s;
     }
-    rsrt_context *context() { return ctx_; }
+    rsrt_context *context(uint32_t i = 0) { return rsrt_multi_context(m_, i); }
 
 private:
-    void check(rsrt_status st, const char *what)
+    void check(rsrt_status st)
     {
-        if (st != RSRT_OK) throw Error(std::string(what) + ": " + rsrt_last_error(ctx_));
+        if (st != RSRT_OK) throw Error(rsrt_multi_last_error(m_));
     }
     size_t scene_hash() const // SceneState: camera bits + environment index (src/scene.rs:255-262, src/camera.rs:92-100)
     {
@@ -165,7 +172,7 @@ private:
         bytes.append(reinterpret_cast<const char *>(&environment_index), sizeof environment_index);
         return std::hash<std::string>()(bytes);
     }
-    rsrt_context *ctx_ = nullptr;
+    rsrt_multi *m_ = nullptr;
     rsrt_camera_desc camera_{};
     uint32_t width_ = 0, height_ = 0, sample_count_ = 0;
     size_t last_hash_ = 0;

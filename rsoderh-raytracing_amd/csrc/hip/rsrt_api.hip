@@ -464,6 +464,14 @@ struct rsrt_context {
     hipEvent_t last_event = nullptr;
     hipStream_t last_stream = nullptr;
     bool last_valid = false;
+    // multi-GPU (rsrt_comm.h): this context's RCCL communicator (an ncclComm_t), NULL in a world of one
+    void *comm = nullptr;
+    bool comm_owned = false;
+    uint32_t comm_rank = 0, comm_world = 1;
+    struct ReduceEvents { hipEvent_t begin, end; };
+    std::vector<ReduceEvents> pending_reduce;
+    double cum_reduce_ms = 0, base_reduce_ms = 0;
+    uint32_t cum_reduces = 0;
     // scratch for rsrt_resolve_mean_f16 / rsrt_display_srgb8 (grow-only; no per-frame hipMalloc)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -605,8 +613,17 @@ hipEvent_t get_event(rsrt_context *ctx)
 // bound the event pool) — it never touches the "since the previous rsrt_get_stats" window.
 rsrt_status collect_events(rsrt_context *ctx)
 {
-    if (ctx->pending_events.empty()) return RSRT_OK;
+    if (ctx->pending_events.empty() && ctx->pending_reduce.empty()) return RSRT_OK;
     { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
+    for (auto &re : ctx->pending_reduce) {
+        float t = 0;
+        HIP_TRY(ctx, hipEventSynchronize(re.end));
+        HIP_TRY(ctx, hipEventElapsedTime(&t, re.begin, re.end));
+        ctx->cum_reduce_ms += t;
+        ctx->event_pool.push_back(re.begin);
+        ctx->event_pool.push_back(re.end);
+    }
+    ctx->pending_reduce.clear();
     for (auto &pe : ctx->pending_events) {
         float t1 = 0, t2 = 0;
         HIP_TRY(ctx, hipEventSynchronize(pe.end));
@@ -643,6 +660,8 @@ rsrt_status collect_stats(rsrt_context *ctx)
     s.total_ext_rays = c[1];
     s.total_shadow_rays = c[2];
     s.total_kernel_ms = ctx->cum_trace_ms + ctx->cum_resolve_ms;
+    s.reduce_ms = ctx->cum_reduce_ms - ctx->base_reduce_ms;
+    ctx->base_reduce_ms = ctx->cum_reduce_ms;
     for (int i = 0; i < 3; i++) ctx->base_counts[i] = c[i];
     ctx->base_trace_ms = ctx->cum_trace_ms;
     ctx->base_resolve_ms = ctx->cum_resolve_ms;
@@ -701,6 +720,23 @@ rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context:
     return RSRT_OK;
 }
 
+// rsrt_display_srgb8 on any W*H RGBA32F sum that lives on ctx's device (the multi-GPU frame buffer uses it too)
+rsrt_status display_from(rsrt_context *ctx, const float4 *sum, uint32_t sample_total, uint8_t *host_rgba8, size_t n_bytes)
+{
+    DeviceGuard g(ctx->device);
+    const size_t n = (size_t)ctx->acc_w * ctx->acc_h;
+    if (!host_rgba8 || n_bytes != n * 4 || sample_total == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "display_srgb8: expected %zu bytes and sample_total > 0", n * 4);
+    rsrt_status st = ensure_scratch(ctx, n * sizeof(uchar4));
+    if (st || (st = begin_work(ctx, ctx->stream))) return st;
+    uchar4 *tmp = static_cast<uchar4 *>(ctx->scratch);
+    hipLaunchKernelGGL(rt_display_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sum, n, sample_total, tmp);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(host_rgba8, tmp, n * sizeof(uchar4), hipMemcpyDeviceToHost, ctx->stream));
+    if ((st = end_work(ctx, ctx->stream))) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RSRT_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -753,6 +789,8 @@ void rsrt_context_destroy(rsrt_context *ctx)
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     (void)sync_all(ctx);
+    (void)rsrt_comm_destroy(ctx);
+    for (auto &re : ctx->pending_reduce) { (void)hipEventDestroy(re.begin); (void)hipEventDestroy(re.end); }
     if (ctx->last_event) (void)hipEventDestroy(ctx->last_event);
     (void)hipFree(ctx->scratch);
     for (auto &pe : ctx->pending_events) { (void)hipEventDestroy(pe.begin); (void)hipEventDestroy(pe.traced); (void)hipEventDestroy(pe.end); }
@@ -1108,19 +1146,8 @@ rsrt_status rsrt_resolve_mean_f16(rsrt_context *ctx, uint32_t sample_total, uint
 rsrt_status rsrt_display_srgb8(rsrt_context *ctx, uint32_t sample_total, uint8_t *host_rgba8, size_t n_bytes)
 {
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
-    DeviceGuard g(ctx->device);
     if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
-    const size_t n = (size_t)ctx->acc_w * ctx->acc_h;
-    if (!host_rgba8 || n_bytes != n * 4 || sample_total == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "display_srgb8: expected %zu bytes and sample_total > 0", n * 4);
-    rsrt_status st = ensure_scratch(ctx, n * sizeof(uchar4));
-    if (st || (st = begin_work(ctx, ctx->stream))) return st;
-    uchar4 *tmp = static_cast<uchar4 *>(ctx->scratch);
-    hipLaunchKernelGGL(rt_display_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->accum, n, sample_total, tmp);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(host_rgba8, tmp, n * sizeof(uchar4), hipMemcpyDeviceToHost, ctx->stream));
-    if ((st = end_work(ctx, ctx->stream))) return st;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return RSRT_OK;
+    return display_from(ctx, ctx->accum, sample_total, host_rgba8, n_bytes);
 }
 
 rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t width, uint32_t height, uint32_t sample_begin,
@@ -1137,7 +1164,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
     rsrt_status st = ensure_accumulator(ctx, width, height);
     if (st) return st;
-    if (ctx->pending_events.size() >= 32) { st = collect_events(ctx); if (st) return st; } // bounds the event pool
+    if (ctx->pending_events.size() + ctx->pending_reduce.size() >= 32) { st = collect_events(ctx); if (st) return st; } // bounds the event pool
     if (sample_count == 0) return RSRT_OK;
 
     RenderParams P;
@@ -1345,3 +1372,5 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
 }
 
 } // extern "C"
+
+#include "rsrt_comm.h"

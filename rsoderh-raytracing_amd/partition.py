@@ -25,11 +25,22 @@ def tile_owner_map(width, height, world, tile_w=TILE_W, tile_h=TILE_H):
 
 
 def owned_mask(width, height, rank, world, tile_w=TILE_W, tile_h=TILE_H):
-    return tile_owner_map(width, height, world, tile_w, tile_h) == rank
+    """[H, W] bool: the pixels `rank` renders — the library's own arithmetic (rsrt_partition_mask, pure host code)."""
+    import ctypes as C
+
+    from . import state
+    mask = np.zeros((height, width), np.uint8)
+    n = C.c_uint64(0)
+    rc = state.lib().rsrt_partition_mask(width, height, tile_w, tile_h, rank, world, mask.ctypes.data_as(C.c_void_p), C.byref(n))
+    if rc != 0:
+        raise ValueError("rsrt_partition_mask: bad arguments")
+    assert int(mask.sum()) == n.value
+    return mask.astype(bool)
 
 
 def reduce_accumulators(tensor, dst=0, group=None):
-    """In-place sum of the per-rank accumulators onto rank `dst` (RCCL over xGMI with backend nccl)."""
+    """In-place sum of per-rank accumulators onto rank `dst` through torch.distributed — the CPU (gloo) rehearsal of the
+    exchange step and bench.py's fallback; the product's reduce is rsrt_comm_reduce (RCCL inside librsrt)."""
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM, group=group)

@@ -23,7 +23,11 @@ _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "r
             "rsrt_upload_environment", "rsrt_set_partition", "rsrt_accumulator_resize", "rsrt_accumulator_bind",
             "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_render",
             "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters", "rsrt_display_srgb8",
-            "rsrt_selftest_numerics", "rsrt_build_id"]
+            "rsrt_selftest_numerics", "rsrt_build_id",
+            "rsrt_partition_owner", "rsrt_partition_mask", "rsrt_comm_unique_id", "rsrt_comm_init", "rsrt_comm_reduce", "rsrt_comm_destroy",
+            "rsrt_multi_create", "rsrt_multi_destroy", "rsrt_multi_last_error", "rsrt_multi_size", "rsrt_multi_context",
+            "rsrt_multi_upload_scene", "rsrt_multi_upload_environment", "rsrt_multi_resize", "rsrt_multi_clear", "rsrt_multi_render",
+            "rsrt_multi_synchronize", "rsrt_multi_download", "rsrt_multi_display_srgb8", "rsrt_multi_get_stats"]
 
 
 class RsrtError(RuntimeError):
@@ -39,7 +43,7 @@ class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("ext_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("kernel_ms", C.c_double),
                 ("total_paths", C.c_uint64), ("total_ext_rays", C.c_uint64), ("total_shadow_rays", C.c_uint64),
                 ("total_kernel_ms", C.c_double), ("launches", C.c_uint32), ("_pad", C.c_uint32),
-                ("trace_kernel_ms", C.c_double), ("resolve_kernel_ms", C.c_double)]
+                ("trace_kernel_ms", C.c_double), ("resolve_kernel_ms", C.c_double), ("reduce_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "_pad"}
@@ -83,6 +87,30 @@ def lib():
         L.rsrt_get_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.rsrt_selftest_numerics.argtypes = [C.c_void_p, C.c_void_p]
         L.rsrt_cast_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.rsrt_partition_owner.restype = C.c_uint32
+        L.rsrt_partition_owner.argtypes = [C.c_uint32] * 7
+        L.rsrt_partition_mask.argtypes = [C.c_uint32] * 6 + [C.c_void_p, C.c_void_p]
+        L.rsrt_comm_unique_id.argtypes = [C.c_void_p]
+        L.rsrt_comm_init.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.rsrt_comm_reduce.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rsrt_comm_destroy.argtypes = [C.c_void_p]
+        L.rsrt_multi_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.rsrt_multi_destroy.argtypes = [C.c_void_p]
+        L.rsrt_multi_last_error.restype = C.c_char_p
+        L.rsrt_multi_last_error.argtypes = [C.c_void_p]
+        L.rsrt_multi_size.restype = C.c_uint32
+        L.rsrt_multi_size.argtypes = [C.c_void_p]
+        L.rsrt_multi_context.restype = C.c_void_p
+        L.rsrt_multi_context.argtypes = [C.c_void_p, C.c_uint32]
+        L.rsrt_multi_upload_scene.argtypes = [C.c_void_p] + [C.c_void_p, C.c_uint32] * 8
+        L.rsrt_multi_upload_environment.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rsrt_multi_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.rsrt_multi_clear.argtypes = [C.c_void_p]
+        L.rsrt_multi_render.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7
+        L.rsrt_multi_synchronize.argtypes = [C.c_void_p]
+        L.rsrt_multi_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.rsrt_multi_display_srgb8.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+        L.rsrt_multi_get_stats.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -156,6 +184,29 @@ class State:
 
     def set_partition(self, rank, world_size, tile_w=16, tile_h=16):
         self._check(self._L.rsrt_set_partition(self._ctx, rank, world_size, tile_w, tile_h), "rsrt_set_partition")
+
+    # -- multi-GPU, one process per GPU: the RCCL reduce lives in the library (include/rsrt.h) -----
+    @staticmethod
+    def comm_unique_id():
+        """Rank 0: the 128 bytes every rank passes to comm_init (hand them over by any channel)."""
+        L = lib()
+        buf = C.create_string_buffer(128)
+        rc = L.rsrt_comm_unique_id(buf)
+        if rc != 0:
+            raise RsrtError("rsrt_comm_unique_id failed (%d): %s" % (rc, L.rsrt_last_error(None).decode()))
+        return buf.raw
+
+    def comm_init(self, rank, world_size, unique_id):
+        assert len(unique_id) == 128
+        self._check(self._L.rsrt_comm_init(self._ctx, rank, world_size, C.create_string_buffer(unique_id, 128)), "rsrt_comm_init")
+
+    def comm_reduce(self, root=0, recv_ptr=None, stream=None):
+        """One RCCL reduce(sum) of the accumulators onto `root` (in place unless recv_ptr names a device buffer)."""
+        self._check(self._L.rsrt_comm_reduce(self._ctx, root, C.c_void_p(recv_ptr) if recv_ptr else None,
+                                             C.c_void_p(stream) if stream else None), "rsrt_comm_reduce")
+
+    def comm_destroy(self):
+        self._check(self._L.rsrt_comm_destroy(self._ctx), "rsrt_comm_destroy")
 
     # -- State::resize / update / render --------------------------------------------------------
     def resize(self, width, height):
@@ -250,3 +301,71 @@ class State:
         out = np.zeros(len(o), T.HIT)
         self._check(self._L.rsrt_cast_rays(self._ctx, len(o), _p(o), _p(d), mode, flags, _p(out)), "rsrt_cast_rays")
         return out
+
+
+class MultiState:
+    """`State` over a LIST of devices of one node, driven by one thread (rsrt_multi_*, include/rsrt.h): device i renders
+    tiles t % n == i, the frame is reduced onto devices[0] by RCCL inside the library when it is asked for."""
+
+    def __init__(self, scene, environments, width, height, devices=(0,), camera=None):
+        self._L = lib()
+        self._m = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self._L.rsrt_multi_create(devs, len(devices), C.byref(self._m))
+        if rc != 0:
+            raise RsrtError("rsrt_multi_create failed (%d): %s" % (rc, self._L.rsrt_multi_last_error(None).decode()))
+        a = [scene.materials, scene.spheres, scene.planes, scene.vertices, scene.normals, scene.triangles, scene.primitives, scene.bvh_nodes]
+        args = []
+        for arr in a:
+            arr = np.ascontiguousarray(arr)
+            args += [_p(arr), len(arr)]
+        self._check(self._L.rsrt_multi_upload_scene(self._m, *args), "rsrt_multi_upload_scene")
+        for i, env in enumerate(environments if isinstance(environments, (list, tuple)) else [environments]):
+            rgba, alias = np.ascontiguousarray(env.rgba, dtype=np.float32), np.ascontiguousarray(env.alias)
+            self._check(self._L.rsrt_multi_upload_environment(self._m, i, env.width, env.height, _p(rgba), _p(alias)), "rsrt_multi_upload_environment")
+        self._check(self._L.rsrt_multi_resize(self._m, width, height), "rsrt_multi_resize")
+        self.width, self.height = width, height
+        self.camera = np.array(camera if camera is not None else scene.camera_uniform()).view(T.CAMERA).reshape(1).copy()
+        self.max_bounces, self.environment_index, self.flags, self.sample_count = 10, 0, 0, 0
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RsrtError("%s failed (%d): %s" % (what, rc, self._L.rsrt_multi_last_error(self._m).decode()))
+
+    def close(self):
+        if self._m:
+            self._L.rsrt_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def size(self):
+        return self._L.rsrt_multi_size(self._m)
+
+    def clear(self):
+        self._check(self._L.rsrt_multi_clear(self._m), "rsrt_multi_clear")
+        self.sample_count = 0
+
+    def render_samples(self, n):
+        self._check(self._L.rsrt_multi_render(self._m, _p(self.camera), self.width, self.height, self.sample_count, n, self.max_bounces,
+                                              self.environment_index, self.flags), "rsrt_multi_render")
+        self.sample_count += n
+
+    def download(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._L.rsrt_multi_download(self._m, _p(out), out.size), "rsrt_multi_download")
+        return out
+
+    def display_srgb8(self):
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        self._check(self._L.rsrt_multi_display_srgb8(self._m, self.sample_count, _p(out), out.size), "rsrt_multi_display_srgb8")
+        return out
+
+    def stats(self):
+        s = Stats()
+        self._check(self._L.rsrt_multi_get_stats(self._m, C.byref(s)), "rsrt_multi_get_stats")
+        return s.as_dict()
