@@ -19,8 +19,8 @@ roofline: the kernel's scene is LDS-resident and its environment
 roof it is under; FP32 VALU issue is.  `frac` = useful f32 lane-instructions per SIMD-cycle / 32 (a SIMD retires
 at most one wave64 VALU instruction per 2 cycles = 32 lanes per cycle), from rocprofv3 PMC counters collected
 LIVE by this run: before the GPU is touched, rank 0 (N = 1) starts `rocprofv3 --kernel-trace --pmc ... -- python3
-bench.py --pmc-child` three times (separate passes: SQ + GRBM, FETCH_SIZE + LDS, WRITE_SIZE + TCC), each rendering
-one frame of the same workload with the same library.  If rocprofv3 cannot run, the committed counters of
+bench.py --pmc-child` four times (separate passes: SQ + GRBM, FETCH_SIZE + LDS, WRITE_SIZE + TCC hit / miss, read
+requests by size), each rendering one frame of the same workload with the same library.  If rocprofv3 cannot run, the committed counters of
 profiles/pmc_house_1080p_8b.json are used — but only when they were taken on the same kernel sources
 (rsrt_build_id); otherwise the object says so and carries no fraction.
 """
@@ -46,12 +46,13 @@ LANES_PER_SIMD_CYCLE = 32.0  # wave64 VALU instruction = 2 cycles on a SIMD32 (g
 MAX_CLOCK_HZ = 2.4e9
 LDS_ARRAY_CYCLES_PER_CU_CYCLE = 1.0
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_house_1080p_8b.json")
-PMC_PASSES = [
+PMC_PASSES = [  # pass 0 is what the fraction needs; the others are reported when they succeed
     ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
      "SQ_BUSY_CYCLES", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"],
     ["FETCH_SIZE", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
      "SQ_WAVES"],
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
+    ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],  # the read requests by size
 ]
 
 
@@ -77,6 +78,32 @@ def cpu_model():
     return "unknown"
 
 
+def effective_cores():
+    """The cores this process may really use: logical CPUs, capped by the affinity mask and by the cgroup's CPU quota
+    (the GPU box shows 256 logical CPUs of an EPYC 9575F pair to a container that is given 16 of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], float(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                    period = float(f2.read().split()[0])
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(-(-float(quota) // period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_leg(scene, env, width, height, bounces, log):
     """cpu_baseline leg (rank 0, N = 1 only): the oracle port on the host cores, bounded sample.  BASELINE.md §2:
     config 1 (default.toml 256x256, 4 spp, 3 bounces) timed in full; the bench workload on >= 4 spp, scaled."""
@@ -85,7 +112,7 @@ def cpu_leg(scene, env, width, height, bounces, log):
     import util
     import rsoderh_raytracing_amd as R
     osc, oenv, cam = util.oracle_scene(scene), util.oracle_env(env), scene.camera_uniform().view(oracle.CAMERA)
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     # counts for the algorithmic-byte model: the traversal the kernel executes — every node the reference visits for
     # extension rays, any-hit exit for shadow rays (pruning is not exactly result-preserving)
     t = time.time()
@@ -124,8 +151,14 @@ def cpu_leg(scene, env, width, height, bounces, log):
             "single_thread_mrays_s": (s1["ext_rays"] + s1["shadow_rays"]) / dt1 / 1e6,
             "ms_per_frame_extrapolated": dt / spp * 256 * 1e3, "extrapolation_factor": 256.0 / spp,
             "config1_default_256x256_4spp_3b": {"ms": best * 1e3, "mrays_s": c1_rays / best / 1e6, "rays": c1_rays, "timed": "in full, best of 3"},
-            "cpu_model": cpu_model(), "seconds": dt}
+            "cpu_model": cpu_model(), "logical_cpus": os.cpu_count(), "seconds": dt,
+            "cores_note": "threads = logical CPUs capped by the affinity mask and the container's CPU quota"}
     return base, per_path, counts
+
+
+def scene_path(name):
+    """--scene: a name under tests/golden/assets/scenes/ or the path of a .toml (tools/make_big_scene.py)."""
+    return name if name.endswith(".toml") else os.path.join(ROOT, "tests", "golden", "assets", "scenes", name + ".toml")
 
 
 # ---------------------------------------------------------------------------------------------- PMC (rocprofv3)
@@ -133,7 +166,7 @@ def pmc_child(args):
     """Runs under rocprofv3: ONE frame of the workload through the C-ABI, nothing else (no torch)."""
     import rsoderh_raytracing_amd as R
     from rsoderh_raytracing_amd import state as S
-    scene = R.Scene.load_toml(os.path.join(ROOT, "tests", "golden", "assets", "scenes", args.scene + ".toml"))
+    scene = R.Scene.load_toml(scene_path(args.scene))
     env = R.Environment.synthetic(2048, 1024)
     st = R.State.new(scene, env, args.width, args.height, device=0)
     st.max_bounces = args.bounces
@@ -155,42 +188,44 @@ def collect_pmc(args, log):
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         for i, counters in enumerate(PMC_PASSES):
-            d = os.path.join(tmp, "pass%d" % i)
-            cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                                                                 "--pmc-child", "--scene", args.scene, "--width", str(args.width), "--height", str(args.height),
-                                                                 "--spp", str(args.spp), "--bounces", str(args.bounces)]
-            t = time.time()
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
-            if r.returncode != 0:
-                log("pmc pass %d failed (rc %d): %s" % (i, r.returncode, (r.stderr or r.stdout)[-400:]))
-                return None
-            child = None
-            for line in r.stdout.splitlines():
-                if line.startswith("{") and "build_id" in line:
-                    child = json.loads(line)
-            if child is None:
-                log("pmc pass %d: child printed no result line" % i)
-                return None
-            out["build_id"] = child["build_id"]
-            rows = 0
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                with open(f) as fh:
-                    for row in csv.DictReader(fh):
-                        name = row["Kernel_Name"]
-                        if "rt_render_pool_kernel" in name or "rt_render_kernel" in name:
-                            out["kernel"] = name
-                            out["counters"][row["Counter_Name"]] = out["counters"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-                            out["launch_ms_under_pmc"] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
-                            rows += 1
-                        elif "rt_resolve_kernel" in name:
-                            out["resolve"][row["Counter_Name"]] = out["resolve"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-            if rows == 0:
-                log("pmc pass %d: no counter rows for the render kernel" % i)
-                return None
-            log("pmc pass %d (%s ...): %.1f s" % (i, counters[0], time.time() - t))
-    except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
-        log("pmc: %r" % (e,))
-        return None
+            try:
+                d = os.path.join(tmp, "pass%d" % i)
+                cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                                                                     "--pmc-child", "--scene", args.scene, "--width", str(args.width), "--height", str(args.height),
+                                                                     "--spp", str(args.spp), "--bounces", str(args.bounces)]
+                t = time.time()
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+                if r.returncode != 0:
+                    raise RuntimeError("rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
+                child = None
+                for line in r.stdout.splitlines():
+                    if line.startswith("{") and "build_id" in line:
+                        child = json.loads(line)
+                if child is None:
+                    raise RuntimeError("child printed no result line")
+                if out["build_id"] not in (None, child["build_id"]):
+                    raise RuntimeError("library changed between passes")
+                out["build_id"] = child["build_id"]
+                rows = 0
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    with open(f) as fh:
+                        for row in csv.DictReader(fh):
+                            name = row["Kernel_Name"]
+                            if "rt_render_pool_kernel" in name or "rt_render_kernel" in name:
+                                out["kernel"] = name
+                                out["counters"][row["Counter_Name"]] = out["counters"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                                if i == 0:
+                                    out["launch_ms_under_pmc"] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+                                rows += 1
+                            elif "rt_resolve_kernel" in name:
+                                out["resolve"][row["Counter_Name"]] = out["resolve"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                if rows == 0:
+                    raise RuntimeError("no counter rows for the render kernel")
+                log("pmc pass %d (%s ...): %.1f s" % (i, counters[0], time.time() - t))
+            except (OSError, subprocess.SubprocessError, ValueError, KeyError, RuntimeError) as e:
+                log("pmc pass %d (%s ...) failed: %s" % (i, counters[0], e))
+                if i == 0:
+                    return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out["source"] = "live: rocprofv3 --kernel-trace --pmc, %d separate passes of one frame each, started by this bench run" % len(PMC_PASSES)
@@ -232,21 +267,33 @@ def roofline_object(pmc, build_id, launch_ms, paths_per_launch, per_path, owned_
                         "wait_any_frac_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
                         "wait_inst_any_frac_of_wave_cycles": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                         "salu_per_valu": c["SQ_INSTS_SALU"] / insts}})
-    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        # FETCH_SIZE / WRITE_SIZE are KiB at the L2's fabric side (Infinity-Cache hits included).  gfx950 tallies a 128-byte
-        # read request as 64 bytes: the resolve kernel of the same pass streams a KNOWN byte count (12 B x paths) and
-        # calibrates the factor (2.0 on every run so far); the render kernel's reads are 128-byte lines too
-        # (tools/fetch_calib.hip), so the same factor applies.
-        known = 12.0 * paths_per_launch
-        r_fetch = pmc["resolve"].get("FETCH_SIZE", 0.0) * 1024.0
-        factor = known / r_fetch if r_fetch > 0 else 2.0
-        fetch, write = c["FETCH_SIZE"] * 1024.0 * factor, c["WRITE_SIZE"] * 1024.0
+    if "WRITE_SIZE" in c and ("FETCH_SIZE" in c or "TCC_EA0_RDREQ_128B_sum" in c):
+        # WRITE_SIZE (KiB) is exact on gfx950; FETCH_SIZE = RDREQ x 64 B tallies a 128-byte read request as 64 bytes (guide,
+        # HBM section; tools/fetch_calib.hip: coalesced 4 / 12 / 16-byte-per-lane streams read 1/2, a random 16-byte gather
+        # is ONE 64-byte request and reads right).  Exact form: the requests by size, 128 x n128 + 64 x n64 + 32 x n32.
+        # Cross-check: rt_resolve_kernel of the same pass streams a KNOWN 12 B x paths.  All at the L2's fabric side:
+        # Infinity-Cache hits are included.
+        write = c["WRITE_SIZE"] * 1024.0
+        hbm = {"write_bytes_per_launch": write}
+        if "TCC_EA0_RDREQ_128B_sum" in c:
+            n128, n64, n32 = c["TCC_EA0_RDREQ_128B_sum"], c["TCC_EA0_RDREQ_64B_sum"], c["TCC_EA0_RDREQ_32B_sum"]
+            other = c["TCC_EA0_RDREQ_sum"] - n128 - n64 - n32
+            fetch = 128.0 * n128 + 64.0 * (n64 + max(other, 0.0)) + 32.0 * n32
+            hbm.update({"fetch_bytes_per_launch": fetch, "fetch_from": "TCC_EA0_RDREQ by request size: 128 B x %.4g + 64 B x %.4g + 32 B x %.4g" % (n128, n64, n32)})
+            if pmc["resolve"].get("TCC_EA0_RDREQ_128B_sum"):
+                r = pmc["resolve"]
+                hbm["resolve_kernel_check"] = {"known_bytes": 12.0 * paths_per_launch,
+                                               "counted_bytes": 128.0 * r["TCC_EA0_RDREQ_128B_sum"] + 64.0 * r.get("TCC_EA0_RDREQ_64B_sum", 0.0) + 32.0 * r.get("TCC_EA0_RDREQ_32B_sum", 0.0)}
+        else:
+            fetch = c["FETCH_SIZE"] * 1024.0 * 2.0
+            hbm.update({"fetch_bytes_per_launch": fetch, "fetch_from": "FETCH_SIZE x 2 (upper bound: every request taken as 128 bytes)"})
+        if "FETCH_SIZE" in c:
+            hbm["FETCH_SIZE_uncorrected_bytes"] = c["FETCH_SIZE"] * 1024.0
         ro["traffic"] = fetch + write
-        ro["hbm"] = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "fetch_size_correction": factor,
-                     "correction_source": "rt_resolve_kernel of the same PMC pass: %.3e known bytes / %.3e counted" % (known, r_fetch),
-                     "GB_per_s": (fetch + write) / (launch_ms * 1e-3) / 1e9, "frac_of_hbm_peak": (fetch + write) / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "compulsory_bytes_per_launch": 12.0 * paths_per_launch + 2 * 2048 * 1024 * 16 + 16.0 * owned_pixels,
-                     "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0 else None}
+        hbm.update({"GB_per_s": (fetch + write) / (launch_ms * 1e-3) / 1e9, "frac_of_hbm_peak": (fetch + write) / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "compulsory_bytes_per_launch": 12.0 * paths_per_launch + 2 * 2048 * 1024 * 16 + 16.0 * owned_pixels,
+                    "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0 else None})
+        ro["hbm"] = hbm
     if "SQ_LDS_IDX_ACTIVE" in c:
         ro["lds"] = {"array_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / (cycles * 256 * LDS_ARRAY_CYCLES_PER_CU_CYCLE),
                      "bank_conflict_frac_of_busy": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], "wave_instructions_per_launch": c["SQ_INSTS_LDS"],
@@ -307,8 +354,7 @@ def main():
 
     import rsoderh_raytracing_amd as R
     from rsoderh_raytracing_amd import partition, state as S
-    scene_file = os.path.join(ROOT, "tests", "golden", "assets", "scenes", args.scene + ".toml")
-    scene = R.Scene.load_toml(scene_file)
+    scene = R.Scene.load_toml(scene_path(args.scene))
     env = R.Environment.synthetic(2048, 1024)
     W, H, spp = args.width, args.height, args.spp
 
@@ -431,7 +477,7 @@ def main():
         result = {"metric": "Mrays/s, house.toml 1920x1080 256spp 8-bounce", "value": value, "unit": "Mrays/s",
                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                  "config": {"workload": "%s.toml %dx%d %d spp %d bounces, synthetic 2048x1024 HDRI env" % (args.scene, W, H, spp, args.bounces),
+                  "config": {"workload": "%s.toml %dx%d %d spp %d bounces, synthetic 2048x1024 HDRI env" % (os.path.basename(args.scene).replace(".toml", ""), W, H, spp, args.bounces),
                              "parallelism": ("tiles16x16-interleaved x%d, one reduce(sum) per frame via %s" % (world, {"rccl": "librsrt rsrt_comm_reduce (RCCL)", "torch-nccl": "torch.distributed nccl", "gloo": "gloo on the host (rehearsal)"}[collective]))
                              if world > 1 else "single GPU",
                              "rays_per_frame": rays_total / args.steps, "paths_per_frame": paths_total / args.steps},

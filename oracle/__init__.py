@@ -75,7 +75,9 @@ _libs = {}
 
 
 def lib(fast=False):
-    name = "liboracle_fast.so" if fast else "liboracle.so"
+    """fast: False = strict build (defines the golden values), True = -O3 twin (bit-identical), "libm" = the
+    sensitivity build (libm transcendentals, free contraction: NOT a parity reference)."""
+    name = "liboracle_libm.so" if fast == "libm" else ("liboracle_fast.so" if fast else "liboracle.so")
     if name in _libs:
         return _libs[name]
     path = os.path.join(_HERE, name)

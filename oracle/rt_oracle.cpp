@@ -18,6 +18,19 @@
 #include "rt_oracle.h"
 #include "../include/rsrt_detmath.h"
 
+// -DORC_LIBM (liboracle_libm.so): the same restatement with the numerics an implementation is FREE to choose under
+// WGSL chosen differently — the platform libm's sinf / cosf / atan2f / asinf instead of rsrt_detmath.h, and (by the
+// Makefile) -ffp-contract=fast, so the compiler fuses multiply-adds wherever it likes.  It is NOT the parity
+// reference; tests/test_numerics_sensitivity.py measures how far such an "honest but not bit-compatible"
+// implementation lands from the strict one, i.e. what north_star's 1e-3 RMSE tolerance can and cannot absorb.
+#ifdef ORC_LIBM
+#include <cmath>
+#define rsrt_sinf sinf
+#define rsrt_cosf cosf
+#define rsrt_atan2f atan2f
+#define rsrt_asinf asinf
+#endif
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>

@@ -291,9 +291,10 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_resolve_kernel(RenderParams P, fl
     const float *src = P.sample_buf + (size_t)slot * 3u;
     const size_t step = (size_t)P.n_slots * 3u;
     for (uint32_t k = 0; k < P.sample_count; k++, src += step) {
-        a.x = a.x + src[0];
-        a.y = a.y + src[1];
-        a.z = a.z + src[2];
+        const rt_f3v v = __builtin_nontemporal_load(reinterpret_cast<const rt_f3v_a4 *>(src)); // read once, never again
+        a.x = a.x + v.x;
+        a.y = a.y + v.y;
+        a.z = a.z + v.z;
     }
     a.w = 1.0f;
     accum[(size_t)py * P.width + px] = a;
@@ -387,10 +388,10 @@ struct Env {
 
 } // namespace
 
-// Kernel variants (RSRT_KERNEL): 0 = lockstep megakernel (first kernel); 1, 2 = stage-scheduled wave-pool kernel
-// with 192 / 160 path slots per wave (160: five workgroups per CU fit in LDS).
-#define RT_N_VARIANTS 3
-static const uint32_t kVariantPool[RT_N_VARIANTS] = {0, 192, 160};
+// Kernel variants (RSRT_KERNEL): 0 = lockstep megakernel (first kernel); 1, 2, 3 = stage-scheduled wave-pool kernel
+// with 192 / 160 / 128 path slots per wave (160: five workgroups per CU fit in LDS; 128: a smaller path-state arena).
+#define RT_N_VARIANTS 4
+static const uint32_t kVariantPool[RT_N_VARIANTS] = {0, 192, 160, 128};
 template <int SV, uint32_t BLOCK, uint32_t POOL>
 static const void *pool_function(int trav)
 {
@@ -406,6 +407,7 @@ static const void *variant_function(int kv, int sv, int trav)
     if (kv == 0) return sv == 1 ? reinterpret_cast<const void *>(&rt_render_kernel<true>) : reinterpret_cast<const void *>(&rt_render_kernel<false>);
     if (sv == 2) return pool_function<2, 1024, 160>(std::min(trav, 1));
     if (kv == 1) return sv == 1 ? pool_function<1, RT_BLOCK, 192>(trav) : pool_function<0, RT_BLOCK, 192>(trav);
+    if (kv == 3) return sv == 1 ? pool_function<1, RT_BLOCK, 128>(trav) : pool_function<0, RT_BLOCK, 128>(trav);
     return sv == 1 ? pool_function<1, RT_BLOCK, 160>(trav) : pool_function<0, RT_BLOCK, 160>(trav);
 }
 
@@ -1215,7 +1217,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     if (sv == 2 && (kv == 0 || !ctx->allow_hybrid)) { sv = 0; P.scene.lds_float4s = 0; } // the first kernel has no hybrid form
     const uint32_t pool = sv == 2 ? 160u : kVariantPool[kv];
     const uint32_t block = sv == 2 ? 1024u : (uint32_t)RT_BLOCK;
-    const int trav = (ctx->max_traversal >= 2 && P.scene.flat_ok) ? 2 : ((ctx->max_traversal >= 1 && P.scene.typed_leaves) ? 1 : 0);
+    const int trav = (ctx->max_traversal >= 2 && P.scene.flat_ok && max_bounces <= RT_FLAT_MAX_BOUNCES) ? 2 : ((ctx->max_traversal >= 1 && P.scene.typed_leaves) ? 1 : 0);
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
                                 : scene_bytes + (size_t)(block / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
@@ -1231,7 +1233,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     }
 
     if (kv != 0) { // cold path-state arena: one block of columns per wave that can be resident
-        const size_t need_cold = (size_t)ctx->cus * bpc * (block / RT_WAVE) * C_COUNT * pool * sizeof(uint32_t);
+        const size_t need_cold = (size_t)ctx->cus * bpc * (block / RT_WAVE) * pool_cold_columns(trav) * pool * sizeof(uint32_t);
         if (need_cold > ctx->cold_bytes) {
             if ((st = sync_all(ctx))) return st;
             if (ctx->cold_state) { (void)hipFree(ctx->cold_state); ctx->cold_state = nullptr; ctx->cold_bytes = 0; }

@@ -398,6 +398,42 @@ RT_DEV float environment_pixel_solid_angle(float v, const DevEnv &e) // :739-749
     float sin_t = fmax_(1.0e-6f, rsrt_sinf(theta));
     return e.dphi_dtheta * sin_t; // (d_phi * d_theta) * sin_t
 }
+// Environment gathers (texels, alias entries): 64 MiB of tables read at random, 128 bytes fetched per 16-byte record.
+// RT_ENV_NT: 0 default cache policy | 1 every gather non-temporal | 2 only the alias-slot gather of sample_environment
+// (index = u * N: uniformly random, never reused), the pick-dependent gathers (the few hundred texels of the sun take
+// ~90 % of the picks) stay cacheable.  A/B of what the stream does to the L2 share of the path-state arena.
+#ifndef RT_ENV_NT
+#define RT_ENV_NT 0
+#endif
+typedef float rt_f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t rt_u4v __attribute__((ext_vector_type(4)));
+RT_DEV float4 env_texel(const DevEnv &e, size_t i)
+{
+#if RT_ENV_NT == 1
+    const rt_f4v v = __builtin_nontemporal_load(reinterpret_cast<const rt_f4v *>(e.rgba + i));
+    return float4{v.x, v.y, v.z, v.w};
+#else
+    return e.rgba[i];
+#endif
+}
+RT_DEV uint4 env_alias_stream(const DevEnv &e, size_t i) // the uniformly random slot of the alias method
+{
+#if RT_ENV_NT
+    const rt_u4v v = __builtin_nontemporal_load(reinterpret_cast<const rt_u4v *>(e.alias + i));
+    return uint4{v.x, v.y, v.z, v.w};
+#else
+    return e.alias[i];
+#endif
+}
+RT_DEV uint4 env_alias(const DevEnv &e, size_t i)
+{
+#if RT_ENV_NT == 1
+    const rt_u4v v = __builtin_nontemporal_load(reinterpret_cast<const rt_u4v *>(e.alias + i));
+    return uint4{v.x, v.y, v.z, v.w};
+#else
+    return e.alias[i];
+#endif
+}
 RT_DEV uint32_t clamp_texel(float f, uint32_t n)
 {
     if (!(f > 0.0f)) return 0u;
@@ -413,8 +449,8 @@ RT_DEV V3 sample_env_bilinear(const DevEnv &e, float u, float v)
     float fx = x - xf, fy = y - yf;
     uint32_t x0 = clamp_texel(xf, e.width), x1 = clamp_texel(xf + 1.0f, e.width);
     uint32_t y0 = clamp_texel(yf, e.height), y1 = clamp_texel(yf + 1.0f, e.height);
-    float4 t00 = e.rgba[(size_t)y0 * e.width + x0], t10 = e.rgba[(size_t)y0 * e.width + x1];
-    float4 t01 = e.rgba[(size_t)y1 * e.width + x0], t11 = e.rgba[(size_t)y1 * e.width + x1];
+    float4 t00 = env_texel(e, (size_t)y0 * e.width + x0), t10 = env_texel(e, (size_t)y0 * e.width + x1);
+    float4 t01 = env_texel(e, (size_t)y1 * e.width + x0), t11 = env_texel(e, (size_t)y1 * e.width + x1);
     float gx = 1.0f - fx, gy = 1.0f - fy;
     V3 top = v3(t00.x, t00.y, t00.z) * gx + v3(t10.x, t10.y, t10.z) * fx;
     V3 bot = v3(t01.x, t01.y, t01.z) * gx + v3(t11.x, t11.y, t11.z) * fx;
@@ -425,7 +461,7 @@ RT_DEV float environment_direction_pdf(const DevEnv &e, V3 dir, float u, float v
     uint32_t x = min(f2u(u * e.wf), e.width - 1u);
     uint32_t y = min(f2u(v * e.hf), e.height - 1u);
     uint32_t index = x + y * e.width;
-    float pmf = as_f(e.alias[index].z);
+    float pmf = as_f(env_alias(e, index).z);
     return pmf / environment_pixel_solid_angle(v, e);
 }
 struct EnvironmentSample {
@@ -436,7 +472,7 @@ RT_DEV EnvironmentSample sample_environment(const DevEnv &e, uint32_t &rng) // :
 {
     uint32_t length = e.width * e.height;
     uint32_t index = min(f2u(random_uniform(rng) * (float)length), length - 1u);
-    uint4 entry = e.alias[index];
+    uint4 entry = env_alias_stream(e, index);
     float u2 = random_uniform(rng);
     uint32_t pick = (u2 < as_f(entry.x)) ? index : entry.y;
     uint32_t x, y; // pick % width, pick / width
@@ -448,7 +484,7 @@ RT_DEV EnvironmentSample sample_environment(const DevEnv &e, uint32_t &rng) // :
     EnvironmentSample s;
     s.direction = equirectangular_uv_to_direction(u, v);
     s.radiance = sample_env_bilinear(e, u, v);
-    float pmf = (pick == index) ? as_f(entry.z) : as_f(e.alias[pick].z);
+    float pmf = (pick == index) ? as_f(entry.z) : as_f(env_alias(e, pick).z);
     s.pdf = pmf / environment_pixel_solid_angle(v, e);
     return s;
 }

@@ -46,20 +46,29 @@ enum CtBits : uint32_t {
     CT_SHIFT = 7u
 };
 enum ColdField {
-    C_TX, C_TY, C_TZ, C_LX, C_LY, C_LZ, C_NEEX, C_NEEY, C_NEEZ, C_LASTPDF, C_RNG, C_BOUNCE, C_OUT,
-    C_REF, // tree-walk traversals only: best hit of the extension ray, record | source << 30 (the flat traversal keeps it in H_CT)
+    C_TX, C_TY, C_TZ, C_LX, C_LY, C_LZ, C_NEEX, C_NEEY, C_NEEZ, C_LASTPDF, C_RNG, C_OUT,
+    C_COUNT_FLAT, // the flat traversal stops here: its bounce count and hit record ride in the idle cursor bits of H_CT
+    C_BOUNCE = C_COUNT_FLAT,
+    C_REF, // tree-walk traversals only: best hit of the extension ray, record | source << 30
     C_COUNT
 };
+// RT_COLD_COMPACT=0 restores 14 cold columns for every traversal (A/B of the arena's L2 footprint)
+#ifndef RT_COLD_COMPACT
+#define RT_COLD_COMPACT 1
+#endif
+#define RT_FLAT_BOUNCE_SHIFT 8u     // flat traversal, H_CT payload: hit record (6-bit index | 2-bit source) | bounce << 8
+#define RT_FLAT_MAX_BOUNCES 0xffffu // 16 bits of the 25; rsrt_render picks a tree-walk kernel beyond that
+__host__ __device__ constexpr uint32_t pool_cold_columns(int trav) { return (RT_COLD_COMPACT && trav == 2) ? (uint32_t)C_COUNT_FLAT : (uint32_t)C_COUNT; }
 enum PoolTag { TAG_FREE = 0, TAG_TRACE = 1, TAG_MISS = 2, TAG_SHADE = 3, TAG_FINISH = 4, TAG_IDLE = 5 };
 enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_FINISH = 4, ST_COUNT = 5 };
 
-template <uint32_t POOL>
+template <uint32_t POOL, int TRAV>
 struct PoolLayout {
     static constexpr uint32_t kSlotsPerLane = (POOL + 63u) / 64u;
     static constexpr uint32_t kHotDwords = H_COUNT * POOL;
     static constexpr uint32_t kListDwords = 64u;
     static constexpr uint32_t kWaveLdsDwords = kHotDwords + kListDwords;
-    static constexpr uint32_t kWaveColdDwords = C_COUNT * POOL;
+    static constexpr uint32_t kWaveColdDwords = pool_cold_columns(TRAV) * POOL;
 };
 
 RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE, MISS, SHADE, FINISH; IDLE -> ST_COUNT (none)
@@ -76,6 +85,29 @@ RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
     } while (0)
 
+// A finished path's radiance goes to the sample buffer once and is read once, by rt_resolve_kernel, long after: a
+// write-once stream that has no business occupying L2 lines the path-state arena wants.
+//   RT_SAMPLE_STORE  0 three plain dword stores | 1 one plain 12-byte store | 2 one non-temporal 12-byte store |
+//                    3 one write-through 12-byte store whose line is dropped from L2 (sc1)
+#ifndef RT_SAMPLE_STORE
+#define RT_SAMPLE_STORE 2
+#endif
+typedef float rt_f3v __attribute__((ext_vector_type(3)));
+typedef rt_f3v rt_f3v_a4 __attribute__((aligned(4)));
+RT_DEV void store_sample(float *dst, V3 L)
+{
+#if RT_SAMPLE_STORE == 0
+    dst[0] = L.x; dst[1] = L.y; dst[2] = L.z;
+#elif RT_SAMPLE_STORE == 1
+    *reinterpret_cast<rt_f3v_a4 *>(dst) = rt_f3v{L.x, L.y, L.z};
+#elif RT_SAMPLE_STORE == 2
+    __builtin_nontemporal_store(rt_f3v{L.x, L.y, L.z}, reinterpret_cast<rt_f3v_a4 *>(dst));
+#else
+    const rt_f3v v = {L.x, L.y, L.z};
+    asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+#endif
+}
+
 #ifndef RT_POOL_WAVES_PER_SIMD
 #define RT_POOL_WAVES_PER_SIMD 4
 #endif
@@ -91,7 +123,8 @@ template <> struct PoolView<2> { typedef SceneViewHybrid type; static __device__
 template <int SV, uint32_t BLOCK, uint32_t POOL, int TRAV>
 __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
 {
-    typedef PoolLayout<POOL> L;
+    typedef PoolLayout<POOL, TRAV> L;
+    constexpr bool kBounceInCt = pool_cold_columns(TRAV) == (uint32_t)C_COUNT_FLAT; // no C_BOUNCE / C_REF column
     const DevScene &sc = P.scene;
     if (SV != 0) stage_scene_lds(sc);
     const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
@@ -201,7 +234,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                         SETC(C_LX, slot, 0.0f); SETC(C_LY, slot, 0.0f); SETC(C_LZ, slot, 0.0f);
                         SETC(C_LASTPDF, slot, 1.0f);
                         COLD(C_RNG, slot) = ps.rng;
-                        COLD(C_BOUNCE, slot) = 0u;
+                        if (!kBounceInCt) COLD(C_BOUNCE, slot) = 0u;
                         COLD(C_OUT, slot) = srel * P.n_slots + chunk_tile_slot0 + p;
                         SET_CT(slot, 0u, F_EXT, TAG_TRACE);
                         n_paths++;
@@ -227,7 +260,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 const V3 d = v3(HOTF(dcol, slot), HOTF(dcol + 1u, slot), HOTF(dcol + 2u, slot));
                 // resume (or start: cur = root, best = INFINITY) the traversal
                 Hit h;
-                uint32_t cur = ct >> CT_SHIFT;
+                uint32_t cur = kBounceInCt ? 0u : (ct >> CT_SHIFT); // (flat: every ray finishes in one call, the bits carry the bounce count)
                 h.src = SRC_BVH;
                 h.t = HOTF(H_T, slot); h.ref = 0; h.u = h.v = 0.0f; // ref of an earlier call stays in the cold column unless beaten
                 const float t_in = h.t;
@@ -241,13 +274,13 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     n_shadow++;
                     SETH(H_T, slot, RT_INFINITY); // the extension ray starts fresh
                     const uint32_t fl = (ct & (F_EXT | F_NEE)) | (h.t < RT_INFINITY ? (uint32_t)F_OCCLUDED : 0u);
-                    SET_CT(slot, 0u, fl, (ct & F_EXT) ? TAG_TRACE : TAG_FINISH);
+                    SET_CT(slot, kBounceInCt ? (ct >> CT_SHIFT) : 0u, fl, (ct & F_EXT) ? TAG_TRACE : TAG_FINISH); // (keeps the bounce bits)
                 } else {
                     n_ext++;
                     SETH(H_T, slot, h.t);
                     if (TRAV != 2 && h.t < t_in) COLD(C_REF, slot) = h.ref; // this call found a closer hit
                     // the flat traversal's records fit the idle cursor bits: no cold column
-                    SET_CT(slot, TRAV == 2 ? h.ref : 0u, ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
+                    SET_CT(slot, (TRAV == 2 ? h.ref : 0u) | (kBounceInCt ? (ct >> CT_SHIFT) : 0u), ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
                 }
             }
         } else if (best == ST_MISS) {
@@ -271,7 +304,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 if (h.did_hit()) { // SHADE takes it from here (and settles the pending NEE term)
                     SETH(H_T, slot, h.t);
                     if (TRAV == 2) {
-                        SET_CT(slot, h.ref | (h.src << 6), ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
+                        SET_CT(slot, h.ref | (h.src << 6) | (kBounceInCt ? (ct >> CT_SHIFT) : 0u), ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
                     } else {
                         COLD(C_REF, slot) = h.ref | (h.src << 30);
                         SET_CT(slot, 0u, ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
@@ -286,8 +319,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
                     if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot)); // previous vertex, lit
                     Lr = Lr + T * sky * w;
-                    float *dst = P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u;
-                    dst[0] = Lr.x; dst[1] = Lr.y; dst[2] = Lr.z;
+                    store_sample(P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u, Lr);
                     SET_TAG(slot, TAG_FREE);
                 }
             }
@@ -300,7 +332,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 Hit h;
                 h.t = HOTF(H_T, slot);
                 if (TRAV == 2) {
-                    const uint32_t hr = ct >> CT_SHIFT;
+                    const uint32_t hr = (ct >> CT_SHIFT) & 0xffu;
                     h.ref = hr & 63u; h.src = hr >> 6;
                 } else {
                     const uint32_t hr = COLD(C_REF, slot);
@@ -310,7 +342,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 uint32_t rng = COLD(C_RNG, slot);
                 V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
                 V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
-                const uint32_t bounce = COLD(C_BOUNCE, slot) + 1u;
+                const uint32_t bounce = (kBounceInCt ? (ct >> (CT_SHIFT + RT_FLAT_BOUNCE_SHIFT)) : COLD(C_BOUNCE, slot)) + 1u;
                 // the previous vertex's NEE term, lit: :1246-1249 of the previous iteration
                 if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot));
                 const Surface surf = resolve_hit(S, h, o, d);
@@ -345,8 +377,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 }
                 if (bounce >= P.max_bounces) finished = true;
                 if (finished && !want_shadow) {
-                    float *dst = P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u;
-                    dst[0] = Lr.x; dst[1] = Lr.y; dst[2] = Lr.z;
+                    store_sample(P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u, Lr);
                     SET_TAG(slot, TAG_FREE);
                 } else {
                     SETC(C_LX, slot, Lr.x); SETC(C_LY, slot, Lr.y); SETC(C_LZ, slot, Lr.z);
@@ -355,13 +386,14 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                         SETC(C_LASTPDF, slot, bs.pdf);
                         SETC(C_TX, slot, T.x); SETC(C_TY, slot, T.y); SETC(C_TZ, slot, T.z);
                         COLD(C_RNG, slot) = rng;
-                        COLD(C_BOUNCE, slot) = bounce;
+                        if (!kBounceInCt) COLD(C_BOUNCE, slot) = bounce;
                         SETH(H_EX, slot, bs.dir.x); SETH(H_EY, slot, bs.dir.y); SETH(H_EZ, slot, bs.dir.z);
                     }
                     if (want_shadow) { SETH(H_SX, slot, es.direction.x); SETH(H_SY, slot, es.direction.y); SETH(H_SZ, slot, es.direction.z); }
                     SETH(H_OX, slot, surf.point.x); SETH(H_OY, slot, surf.point.y); SETH(H_OZ, slot, surf.point.z); // both rays start at the hit point
                     SETH(H_T, slot, RT_INFINITY);
-                    SET_CT(slot, 0u, (want_shadow ? (uint32_t)F_SHADOW : 0u) | (finished ? 0u : (uint32_t)F_EXT) | (nee_counts ? (uint32_t)F_NEE : 0u), TAG_TRACE);
+                    SET_CT(slot, kBounceInCt ? (bounce << RT_FLAT_BOUNCE_SHIFT) : 0u,
+                           (want_shadow ? (uint32_t)F_SHADOW : 0u) | (finished ? 0u : (uint32_t)F_EXT) | (nee_counts ? (uint32_t)F_NEE : 0u), TAG_TRACE);
                 }
             }
         } else {
@@ -370,8 +402,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 const uint32_t ct = HOT(H_CT, slot);
                 V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
                 if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot));
-                float *dst = P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u;
-                dst[0] = Lr.x; dst[1] = Lr.y; dst[2] = Lr.z;
+                store_sample(P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u, Lr);
                 SET_TAG(slot, TAG_FREE);
             }
         }

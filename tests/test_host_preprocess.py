@@ -133,3 +133,39 @@ def test_first_material_name_wins_and_ints_accepted(tmp_path):
     s = R.Scene.load_toml(str(p))
     assert s.spheres["material_id"][0] == 0 and len(s.materials) == 2
     assert s.camera_desc["fov_y"][0] == np.float32(100) * np.float32(np.pi / 180)
+
+
+def test_obj_with_two_objects_rebases_indices_per_object(tmp_path):
+    """Mesh::load over an OBJ with two `o` objects (src/mesh.rs:36-73): vertices / normals are appended object by
+    object, face indices (global, 1-based, or negative = relative to the end) land on the right rows, the quad is
+    fanned (v0, v1, v2), (v0, v2, v3), lines are dropped, `usemtl` is ignored.  A second mesh object in the same scene
+    starts after the first in the packed arrays (PackedMeshes::pack_meshes, :92-113)."""
+    import shutil
+    shutil.copy(util.ASSETS + "/two_objects.obj", tmp_path / "two_objects.obj")
+    shutil.copy(util.ASSETS + "/cube.obj", tmp_path / "cube.obj")
+    p = tmp_path / "s.toml"
+    p.write_text("[[material]]\nname = \"a\"\ncolor = [1,1,1]\nroughness = 1\nmetallic = 0\nemission = [0,0,0]\n"
+                 "[[material]]\nname = \"b\"\ncolor = [1,0,0]\nroughness = 1\nmetallic = 0\nemission = [0,0,0]\n"
+                 "[[object]]\n[object.Mesh]\nmaterial = \"b\"\npath = \"two_objects.obj\"\n"
+                 "[[object]]\n[object.Mesh]\nmaterial = \"a\"\npath = \"cube.obj\"\n"
+                 "[camera]\npos = [0,1,5]\nyaw = 0\npitch = 0\nfov_y = 60\n")
+    s = R.Scene.load_toml(str(p))
+    assert len(s.vertices) == 8 + 8 and len(s.normals) == 3 + 6 and len(s.triangles) == 4 + 12
+    assert np.array_equal(s.vertices["v"][:8], np.float32([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1], [-1, 2, -1], [1, 2, -1], [0, 3, 0], [0, 2, 1]]))
+    t = s.triangles
+    as_rows = np.stack([t[n] for n in ("vertex_0", "vertex_1", "vertex_2", "normal_0", "normal_1", "normal_2", "material_id")], axis=1)
+    assert as_rows[:4].tolist() == [[0, 1, 2, 0, 0, 0, 1], [0, 2, 3, 0, 0, 0, 1],   # the quad of object 1, fanned
+                                    [4, 5, 6, 1, 1, 1, 1],                           # object 2, global indices 5 6 7 / normal 2
+                                    [4, 7, 6, 2, 2, 2, 1]]                           # object 2, negative indices -4 -1 -2 / normal -1
+    assert as_rows[4:, :3].min() == 8 and as_rows[4:, :3].max() == 15 and as_rows[4:, 3:6].min() == 3  # the cube comes after
+    assert np.all(as_rows[4:, 6] == 0)
+    # and the whole thing renders the same through BVH build + oracle as a restatement check of the packing
+    prims, nodes, depth = oracle.build_bvh(s.spheres.view(oracle.SPHERE), s.plane_descs.view(oracle.PLANE_SRC), s.vertices.view(oracle.VEC3),
+                                           s.triangles.view(oracle.TRIANGLE))
+    assert util.fields_equal(s.primitives, prims) and util.fields_equal(s.bvh_nodes, nodes)
+    # a face that reaches back into the previous object: wavefront_obj's object-relative indices cannot express it
+    bad = tmp_path / "bad.obj"
+    bad.write_text("o a\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\no b\nv 0 0 1\nf 1//1 2//1 4//1\n")
+    p.write_text(p.read_text().replace("two_objects.obj", "bad.obj"))
+    with pytest.raises(R.SceneError, match="index out of range"):
+        R.Scene.load_toml(str(p))
