@@ -56,6 +56,10 @@ PMC_PASSES = [  # pass 0 is what the fraction needs; the others are reported whe
 ]
 
 
+if os.environ.get("RSRT_PMC_EXTRA"):  # diagnosis: more passes, e.g. "TCP_TOTAL_CACHE_ACCESSES_sum,TCP_GATE_EN1_sum" (NOT TA_* / TD_*: they hang rocprofv3 here)
+    PMC_PASSES = PMC_PASSES + [p.split(",") for p in os.environ["RSRT_PMC_EXTRA"].split(";") if p]
+
+
 def algorithmic_bytes(st):
     """SURVEY.md §8(d) per-unit figures applied to instrumented counts (unpruned, any-hit shadow).
     Returns bytes for everything in `st` except the once-per-pixel accumulator write."""
@@ -194,7 +198,7 @@ def collect_pmc(args, log):
                                                                      "--pmc-child", "--scene", args.scene, "--width", str(args.width), "--height", str(args.height),
                                                                      "--spp", str(args.spp), "--bounces", str(args.bounces)]
                 t = time.time()
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=90)
                 if r.returncode != 0:
                     raise RuntimeError("rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
                 child = None

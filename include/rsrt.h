@@ -108,9 +108,17 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx,
 /* -- environment: bind group 0 bindings 3-5 (state.rs:119-132, environments.rs:19-64) --------
  * slot = index into the reference's binding_array / `environments` array.  rgba: width*height*4
  * f32, rows top to bottom, alpha ignored (texture.rs:112-115 writes 0).  alias: width*height
- * entries as AliasTable::build_by_luminance produces (rsrt_host.h has that builder). */
+ * entries as AliasTable::build_by_luminance produces (rsrt_host.h has that builder), or NULL to have the
+ * library build the table on the device (rsrt_environment_build_alias below). */
 rsrt_status rsrt_upload_environment(rsrt_context *ctx, uint32_t slot, uint32_t width, uint32_t height,
                                     const float *rgba, const rsrt_alias_entry *alias);
+/* AliasTable::build_by_luminance (src/environments.rs:96-187) ON THE DEVICE, for the texels already uploaded in `slot`
+ * (SURVEY.md §8 f3): the same bits as the host builder rsrt_alias_table_build (rsrt_host.h) — the sequential f32 sum and
+ * the LIFO Vose pairing are kept sequential, one wave runs them (csrc/hip/rt_alias_device.h).  Replaces the slot's
+ * table; host_out (may be NULL) receives the width*height entries, leftover_out (may be NULL) the count of entries
+ * that kept the default {1, self, 1/N}.  rsrt_upload_environment with alias == NULL uploads the texels and calls this. */
+rsrt_status rsrt_environment_build_alias(rsrt_context *ctx, uint32_t slot, rsrt_alias_entry *host_out, size_t n_entries,
+                                         uint32_t *leftover_out);
 
 /* -- multi-GPU framebuffer ownership (no reference counterpart) ---------------
  * The frame is cut into tile_w x tile_h pixel tiles numbered row-major; this context renders
@@ -210,12 +218,12 @@ rsrt_status rsrt_get_stats(rsrt_context *ctx, rsrt_stats *out);
  * Exists for parity tests of traversal + intersection without the RNG: out records are
  * {did_hit u32, distance f32, hit_point 3xf32, normal 3xf32, material_id u32} = 36 bytes.
  * mode bit 0: 0 = cast_ray (BVH, then the brute-force fallback), 1 = cast_ray_bvh only;
- * mode bits 1-2, the traversal: 0 = threaded tree walk, 1 = the first kernel's stack walk, 2 = tree walk with typed leaf
- *   loops (suzanne in production), 3 = flat loop over the leaf boxes (house, default, cube in production) — the very
- *   device functions rt_render_pool_kernel's TRACE stage calls; a scene that does not qualify for 2 / 3 is
- *   RSRT_ERR_INVALID_ARGUMENT;
- * mode bit 3: read the scene from LDS exactly as the production kernel stages it (whole image, or nodes + escape
- *   links for mid-size scenes) instead of from global memory.  Host pointers. */
+ * mode bits 1-3, the traversal: 0 = threaded tree walk, 1 = the first kernel's stack walk, 2 = tree walk with typed leaf
+ *   loops, 3 = flat loop over the leaf boxes (house, default, cube in production), 4 = fixed-order walk with ties
+ *   decided by tabulated visiting ranks (suzanne and anything bigger in production) — the very device functions
+ *   rt_render_pool_kernel's TRACE stage calls; a scene that does not qualify for 2 / 3 / 4 is RSRT_ERR_INVALID_ARGUMENT;
+ * mode bit 4: read the scene from LDS exactly as the production kernel stages it for that traversal (whole image, or
+ *   for mid-size scenes the nodes + escape links / the pre-order nodes) instead of from global memory.  Host pointers. */
 typedef struct rsrt_hit {
     uint32_t did_hit;
     float distance;

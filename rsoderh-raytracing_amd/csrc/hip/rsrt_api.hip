@@ -67,24 +67,25 @@ __device__ __forceinline__ SceneView<true> make_view<true>(const DevScene &sc)
     v.o_fbs = v.o_mats + 4u * sc.n_materials;
     v.o_fbp = v.o_fbs + 4u * sc.n_spheres;
     v.o_flat = v.o_fbp + 4u * sc.n_planes;
+    v.pnodes = sc.pnodes;
     return v;
 }
 template <>
 __device__ __forceinline__ SceneView<false> make_view<false>(const DevScene &sc)
 {
-    return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.escape, sc.flat_leaves};
+    return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.escape, sc.flat_leaves, sc.pnodes};
 }
 
 __device__ __forceinline__ SceneViewHybrid make_view_hybrid(const DevScene &sc)
 {
-    return SceneViewHybrid{0u, 2u * sc.n_nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes};
+    return SceneViewHybrid{0u, 2u * sc.n_nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.pnodes, sc.lds_float4s};
 }
 
 // Copies the scene image into LDS (the arrays are contiguous in one device allocation, in the order
 // make_view<true> assumes).
 __device__ __forceinline__ void stage_scene_lds(const DevScene &sc)
 {
-    for (uint32_t i = threadIdx.x; i < sc.lds_float4s; i += blockDim.x) rt_smem[i] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < sc.lds_float4s; i += blockDim.x) rt_smem[i] = sc.lds_src[i];
     __syncthreads();
 }
 
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
 }
 
 #include "rt_wavepool.h"
+#include "rt_alias_device.h"
 
 // total = textureLoad(cumulative) + sample, once per sample in order (shader.wgsl:1367-1371)
 __global__ __launch_bounds__(RT_BLOCK) void rt_resolve_kernel(RenderParams P, float4 *accum)
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_resolve_kernel(RenderParams P, fl
 }
 
 // The ray-query probe.  SV / TRAV as in rt_render_pool_kernel (where the scene is read from, which traversal
-// runs); TRAV == 3 is the first kernel's stack walk.  mode bit 0: cast_ray_bvh only (no brute-force fallback).
+// runs); TRAV == 4 is the first kernel's stack walk.  mode bit 0: cast_ray_bvh only (no brute-force fallback).
 template <int SV, int TRAV>
 __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uint32_t n, const float *origins, const float *dirs,
                                                                 uint32_t mode, uint32_t flags, rsrt_hit *out)
@@ -316,14 +318,14 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
     const bool prune = (flags & RSRT_FLAG_PRUNE) != 0;
     Hit h;
     h.t = RT_INFINITY; h.ref = 0; h.src = SRC_BVH; h.u = h.v = 0.0f;
-    if (TRAV == 3) { // the stack traversal of the first kernel
+    if (TRAV == 4) { // the stack traversal of the first kernel
         trace_bvh<false>(S, o, d, prune, stack, RT_BLOCK, h);
     } else { // what the production kernel's TRACE stage runs, resumed until done as the scheduler would
 #ifdef RT_INSTRUMENT
         DbgCounters dbg;
 #endif
         uint32_t cur = 0;
-        while (cur != RT_END) trace_dispatch<(TRAV == 3 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, cur, h);
+        while (cur != RT_END) trace_dispatch<(TRAV == 4 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, cur, h, nullptr);
         if (h.did_hit()) hit_barycentrics(S, h, o, d); // as SHADE does: the traversals do not carry u, v
     }
     if ((mode & 1u) == 0 && !h.did_hit()) { // cast_ray's brute-force fallback (the MISS stage)
@@ -398,6 +400,7 @@ static const void *pool_function(int trav)
     switch (trav) {
     case 0: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 0>);
     case 1: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 1>);
+    case 3: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 3>);
     default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 2>);
     }
 }
@@ -405,7 +408,7 @@ static const void *pool_function(int trav)
 static const void *variant_function(int kv, int sv, int trav)
 {
     if (kv == 0) return sv == 1 ? reinterpret_cast<const void *>(&rt_render_kernel<true>) : reinterpret_cast<const void *>(&rt_render_kernel<false>);
-    if (sv == 2) return pool_function<2, 1024, 160>(std::min(trav, 1));
+    if (sv == 2) return pool_function<2, 1024, 160>(trav == 2 ? 1 : trav); // (the flat loop needs the whole image: never asked for here)
     if (kv == 1) return sv == 1 ? pool_function<1, RT_BLOCK, 192>(trav) : pool_function<0, RT_BLOCK, 192>(trav);
     if (kv == 3) return sv == 1 ? pool_function<1, RT_BLOCK, 128>(trav) : pool_function<0, RT_BLOCK, 128>(trav);
     return sv == 1 ? pool_function<1, RT_BLOCK, 160>(trav) : pool_function<0, RT_BLOCK, 160>(trav);
@@ -418,7 +421,8 @@ static const void *probe_function_sv(int trav)
     case 0: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 0>);
     case 1: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 1>);
     case 2: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, (SV == 2 ? 1 : 2)>); // (flat needs the whole image: never asked for with SV 2)
-    default: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 3>);
+    case 3: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 3>);
+    default: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 4>);
     }
 }
 static const void *probe_function(int sv, int trav)
@@ -437,6 +441,7 @@ struct rsrt_context {
     float4 *scene_blob = nullptr;
     DevScene scene{};
     bool scene_ready = false;
+    uint32_t hybrid_head_f4 = 0, hybrid_pnode_f4 = 0; // mid-size scenes: float4s of nodes + escape links / of the pre-order nodes (0 = too big for LDS)
     // environments
     std::vector<Env> envs;
     // partition
@@ -477,9 +482,10 @@ struct rsrt_context {
     // scratch for rsrt_resolve_mean_f16 / rsrt_display_srgb8 (grow-only; no per-frame hipMalloc)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
-    int blocks_per_cu[9][RT_N_VARIANTS] = {}; // [scene view * 3 + traversal][kernel variant]
+    int blocks_per_cu[12][RT_N_VARIANTS] = {}; // [scene view * 4 + traversal][kernel variant]
     int kernel_variant = 2; // index into kVariantPool
-    int max_traversal = 2; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
+    int max_traversal = 3; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
+    bool allow_flat = true;
     bool allow_hybrid = true;
     uint32_t trace_budget = 12; // traversal steps per TRACE invocation before a ray is re-queued
     unsigned long long debug_words[32] = {0};
@@ -673,6 +679,16 @@ rsrt_status collect_stats(rsrt_context *ctx)
 }
 
 
+// Which traversal TRACE runs (rt_wavepool.h, TRAV): the flat loop where the scene qualifies, else the fixed-order walk,
+// else (leaves longer than 8 primitives) the generic tree walk; RSRT_TRAVERSAL / RSRT_FLAT cap the choice for A/B runs.
+int select_traversal(const rsrt_context *ctx, const DevScene &sc, uint32_t max_bounces)
+{
+    if (ctx->max_traversal >= 2 && ctx->allow_flat && sc.flat_ok && max_bounces <= RT_FLAT_MAX_BOUNCES) return 2;
+    if (ctx->max_traversal >= 3 && sc.typed_leaves) return 3;
+    if (ctx->max_traversal >= 1 && sc.typed_leaves) return 1;
+    return 0;
+}
+
 // One pass of rsrt_render: the path-tracing kernel over P.sample_count samples, then the ordered resolve.
 rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context::PassEvents &pe, const void *kfn, uint32_t block, int bpc,
                          size_t smem, size_t per_sample, uint32_t max_bounces, hipStream_t stream)
@@ -770,15 +786,16 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
         return RSRT_ERR_HIP;
     }
     for (int kv = 0; kv < RT_N_VARIANTS; kv++)
-        for (int m = 0; m < 9; m++) (void)hipFuncSetAttribute(variant_function(kv, m / 3, m % 3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int m = 0; m < 12; m++) (void)hipFuncSetAttribute(variant_function(kv, m / 4, m % 4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *kv = getenv("RSRT_KERNEL")) { // see kVariantPool
         int v = atoi(kv);
         if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
     }
     if (const char *hy = getenv("RSRT_HYBRID")) ctx->allow_hybrid = atoi(hy) != 0; // 0: mid-size scenes read everything from global memory (A/B)
-    if (const char *ty = getenv("RSRT_TRAVERSAL")) ctx->max_traversal = atoi(ty); // cap: 0 generic tree walk, 1 typed leaf loops, 2 flat small-scene loop (A/B)
+    if (const char *ty = getenv("RSRT_TRAVERSAL")) ctx->max_traversal = atoi(ty); // cap: 0 generic tree walk, 1 typed leaf loops, 2 + flat small-scene loop, 3 + fixed-order walk (A/B)
+    if (const char *fl = getenv("RSRT_FLAT")) ctx->allow_flat = atoi(fl) != 0; // 0: small scenes take the walk a big scene would (A/B)
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
-    for (int m = 0; m < 12; m++) (void)hipFuncSetAttribute(probe_function(m / 4, m % 4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int m = 0; m < 15; m++) (void)hipFuncSetAttribute(probe_function(m / 5, m % 5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
     snprintf(buf, sizeof buf, "librsrt 0.1; %s (%s); %d CUs", prop.name, prop.gcnArchName, ctx->cus);
     ctx->description = buf;
@@ -948,9 +965,104 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         }
     }
     const size_t flat_f4 = flat_ok ? 2 * leaf_nodes.size() : 0, rank_f4 = flat_ok ? 32 : 0;
+    // ---- fixed-order traversal (rt_device.h, trace_preorder): per-octant visiting rank of EVERY primitive record — the
+    // position at which the reference's near-child-first walk meets it — which decides equal t whatever order the records
+    // are really tested in; and the skip links of the pre-order node array (next node once an interior node is missed).
+    std::vector<uint32_t> prim_rank(8ull * n_primitives, 0u);
+    for (uint32_t q = 0; q < 8; q++) {
+        std::vector<uint32_t> st{0u};
+        uint32_t pos = 0;
+        while (!st.empty()) {
+            const uint32_t i = st.back();
+            st.pop_back();
+            const rsrt_bvh_node &nd = nodes[i];
+            if (nd.primitives_len != 0) {
+                for (uint32_t k = 0; k < nd.primitives_len; k++) prim_rank[(size_t)q * n_primitives + nd.primitives_or_second_child_index + k] = pos++;
+            } else {
+                const bool far_first = (q >> nd.split_axis) & 1u;
+                const uint32_t first = i + 1, second = nd.primitives_or_second_child_index;
+                st.push_back(far_first ? first : second);
+                st.push_back(far_first ? second : first);
+            }
+        }
+    }
+    // The walk's node array ("pnodes").  Every interior node carries BOTH its links explicitly — where to go when its box
+    // is hit (its first child) and when it is missed (the pre-order successor of its subtree) — and a leaf is followed by
+    // its successor, so the array may be laid out in any order.  It is laid out in two levels: first a TOP BLOCK, the
+    // nodes a ray is most likely to meet (greedy by box surface area from the root: a child's box lies inside its
+    // parent's, so the set is closed under "parent of"), in their pre-order; then everything else, in pre-order.  The
+    // kernel keeps the top block in LDS (one copy per CU) and reads the rest from global memory: on the 15,488-triangle
+    // grid scene 1,400 of 8,731 nodes take ~80 % of the box tests.  Where a leaf's successor is not the next array
+    // element (a subtree leaves or re-enters the top block) a JUMP element is inserted: an interior-type record whose
+    // two links are equal and whose box is never tested.
+    struct PNode { uint32_t old; uint32_t jump_to; }; // old == UINT32_MAX: a jump element to old node `jump_to` (n_nodes = end)
+    std::vector<uint32_t> succ(n_nodes, n_nodes); // pre-order successor of node i's subtree
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> st; // node, what follows its subtree
+        st.push_back({0u, n_nodes});
+        while (!st.empty()) {
+            auto [i, after] = st.back();
+            st.pop_back();
+            succ[i] = after;
+            const rsrt_bvh_node &nd = nodes[i];
+            if (nd.primitives_len == 0) {
+                st.push_back({i + 1, nd.primitives_or_second_child_index}); // the first child's subtree ends where the second child begins
+                st.push_back({nd.primitives_or_second_child_index, after});
+            }
+        }
+    }
+    const uint32_t kTopMax = 1408; // top-block elements that fit beside sixteen path pools: 1408 x 32 B = 44 KB
+    std::vector<PNode> plist;
+    uint32_t top_elems = 0;
+    for (uint32_t want = std::min<uint32_t>(n_nodes, kTopMax);; want = want * 7 / 8) {
+        std::vector<uint8_t> in_top(n_nodes, 0);
+        { // greedy by surface area
+            auto area = [&](uint32_t i) {
+                const double dx = (double)nodes[i].bounds_max[0] - nodes[i].bounds_min[0], dy = (double)nodes[i].bounds_max[1] - nodes[i].bounds_min[1],
+                             dz = (double)nodes[i].bounds_max[2] - nodes[i].bounds_min[2];
+                const double a = dx * dy + dy * dz + dz * dx;
+                return a == a ? a : 0.0;
+            };
+            std::vector<std::pair<double, uint32_t>> heap;
+            heap.push_back({area(0), 0u});
+            uint32_t taken = 0;
+            while (!heap.empty() && taken < want) {
+                std::pop_heap(heap.begin(), heap.end());
+                const uint32_t i = heap.back().second;
+                heap.pop_back();
+                in_top[i] = 1;
+                taken++;
+                if (nodes[i].primitives_len == 0)
+                    for (uint32_t c : {i + 1u, nodes[i].primitives_or_second_child_index}) {
+                        heap.push_back({area(c), c});
+                        std::push_heap(heap.begin(), heap.end());
+                    }
+            }
+        }
+        plist.clear();
+        for (int pass = 0; pass < 2; pass++) { // top block, then the rest; both in pre-order (= index order)
+            std::vector<uint32_t> order;
+            for (uint32_t i = 0; i < n_nodes; i++)
+                if ((in_top[i] != 0) == (pass == 0)) order.push_back(i);
+            for (size_t k = 0; k < order.size(); k++) {
+                const uint32_t i = order[k];
+                plist.push_back({i, 0u});
+                const uint32_t follows = k + 1 < order.size() ? order[k + 1] : 0xffffffffu; // (the rest's first element never follows the top block's last)
+                if (nodes[i].primitives_len != 0 && succ[i] != follows) plist.push_back({0xffffffffu, succ[i]});
+            }
+            if (pass == 0) top_elems = (uint32_t)plist.size();
+        }
+        if (top_elems <= kTopMax || want <= 1) break;
+    }
+    const uint32_t n_pnodes = (uint32_t)plist.size();
+    if (n_pnodes >= RT_END) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh_nodes: %u traversal elements exceed the 25-bit cursor", n_pnodes);
+    std::vector<uint32_t> new_id(n_nodes + 1, n_pnodes); // old node -> element; [n_nodes] = end
+    for (uint32_t e = 0; e < n_pnodes; e++)
+        if (plist[e].old != 0xffffffffu) new_id[plist[e].old] = e;
+    const size_t pnode_f4 = 2ull * n_pnodes, prank_f4 = (8ull * n_primitives + 3) / 4;
     // ---- build the device image: nodes | prims | escape links | tri normals | materials | fb spheres | fb planes
     const size_t n_f4 = 2ull * n_nodes + 4ull * n_primitives + 3ull * n_triangles + 4ull * n_materials + 4ull * n_spheres + 4ull * n_planes + esc_f4 + flat_f4;
-    std::vector<float4> img(n_f4 + rank_f4); // the rank table follows the LDS image
+    std::vector<float4> img(n_f4 + rank_f4 + pnode_f4 + prank_f4); // what follows the LDS image: flat ranks | pre-order nodes | record ranks
     float4 *p = img.data();
     float4 *p_nodes = p;
     bool typed_leaves = true;
@@ -1005,6 +1117,25 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         }
         memcpy(p, flat_rank.data(), flat_rank.size() * sizeof(uint32_t));
     }
+    float4 *p_pnodes = img.data() + n_f4 + rank_f4;
+    for (uint32_t e = 0; e < n_pnodes; e++) {
+        if (plist[e].old == 0xffffffffu) { // jump element: both links equal, box never looked at
+            const uint32_t to = new_id[plist[e].jump_to];
+            p_pnodes[2 * e] = f4(0, 0, 0, u2f(to));
+            p_pnodes[2 * e + 1] = f4(0, 0, 0, u2f(to));
+            continue;
+        }
+        const uint32_t i = plist[e].old;
+        p_pnodes[2 * e] = p_nodes[2 * i];
+        p_pnodes[2 * e + 1] = p_nodes[2 * i + 1];
+        if (nodes[i].primitives_len == 0) { // interior: {min, link when hit}{max, link when missed}
+            p_pnodes[2 * e].w = u2f(new_id[i + 1]);
+            p_pnodes[2 * e + 1].w = u2f(new_id[succ[i]]);
+        } else { // leaf: first record | leaf flag; length | triangle mask << 16 | plane mask << 24 (as in `nodes`)
+            p_pnodes[2 * e].w = u2f(nodes[i].primitives_or_second_child_index | 0x80000000u);
+        }
+    }
+    if (n_primitives) memcpy(p_pnodes + pnode_f4, prim_rank.data(), prim_rank.size() * sizeof(uint32_t));
 
     { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     if (ctx->scene_blob) { (void)hipFree(ctx->scene_blob); ctx->scene_blob = nullptr; }
@@ -1021,6 +1152,9 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.escape = ctx->scene_blob + (p_esc - img.data());
     sc.flat_leaves = ctx->scene_blob + (p_flat - img.data());
     sc.flat_rank = reinterpret_cast<const uint32_t *>(ctx->scene_blob + n_f4);
+    sc.pnodes = ctx->scene_blob + n_f4 + rank_f4;
+    sc.n_pnodes = n_pnodes;
+    sc.prim_rank = reinterpret_cast<const uint32_t *>(ctx->scene_blob + n_f4 + rank_f4 + pnode_f4);
     sc.flat_ok = flat_ok ? 1u : 0u;
     sc.n_leaves = (uint32_t)leaf_nodes.size();
     sc.tri_mask_lo = (uint32_t)tri_mask; sc.tri_mask_hi = (uint32_t)(tri_mask >> 32);
@@ -1033,9 +1167,11 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     if (stack_bytes > 128 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh depth %u exceeds the supported traversal stack", depth);
     sc.lds_float4s = (n_f4 * sizeof(float4) <= 24 * 1024) ? (uint32_t)n_f4 : 0u; // whole image in LDS only while it leaves room for the path pools
     sc.lds_hybrid = 0;
-    if (sc.lds_float4s == 0 && traversal_head_f4 * sizeof(float4) <= 40 * 1024) { // mid-size: nodes + escape links, one big workgroup per CU
-        sc.lds_float4s = (uint32_t)traversal_head_f4;
-        sc.lds_hybrid = 1;
+    sc.lds_src = sc.nodes; // the image starts with the nodes
+    ctx->hybrid_head_f4 = ctx->hybrid_pnode_f4 = 0;
+    if (sc.lds_float4s == 0) { // mid-size: what every box step touches goes to LDS, one big workgroup per CU shares the copy
+        if (traversal_head_f4 * sizeof(float4) <= 40 * 1024) ctx->hybrid_head_f4 = (uint32_t)traversal_head_f4; // nodes + escape links (tree walks)
+        ctx->hybrid_pnode_f4 = 2u * top_elems; // the top block of the fixed-order walk's nodes (all of them when the scene is mid-size)
     }
     ctx->scene_ready = true;
     return RSRT_OK;
@@ -1046,12 +1182,13 @@ rsrt_status rsrt_upload_environment(rsrt_context *ctx, uint32_t slot, uint32_t w
 {
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
     DeviceGuard g(ctx->device);
-    if (!rgba || !alias || width == 0 || height == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "environment: NULL data or zero size");
+    if (!rgba || width == 0 || height == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "environment: NULL data or zero size");
     if ((uint64_t)width * height > 0x7fffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "environment too large");
     if (slot > 63) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "environment slot %u > 63", slot);
     const size_t n = (size_t)width * height;
-    for (size_t i = 0; i < n; i++)
-        if (alias[i].alias_index >= n) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "alias entry %zu: alias_index %u out of range", i, alias[i].alias_index);
+    if (alias)
+        for (size_t i = 0; i < n; i++)
+            if (alias[i].alias_index >= n) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "alias entry %zu: alias_index %u out of range", i, alias[i].alias_index);
     if (ctx->envs.size() <= slot) ctx->envs.resize(slot + 1);
     Env &e = ctx->envs[slot];
     { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
@@ -1061,9 +1198,51 @@ rsrt_status rsrt_upload_environment(rsrt_context *ctx, uint32_t slot, uint32_t w
     HIP_TRY(ctx, hipMalloc(&e.rgba, n * sizeof(float4)));
     HIP_TRY(ctx, hipMalloc(&e.alias, n * sizeof(uint4)));
     HIP_TRY(ctx, hipMemcpy(e.rgba, rgba, n * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(e.alias, alias, n * sizeof(uint4), hipMemcpyHostToDevice));
+    if (alias) {
+        HIP_TRY(ctx, hipMemcpy(e.alias, alias, n * sizeof(uint4), hipMemcpyHostToDevice));
+        e.width = width;
+        e.height = height;
+        return RSRT_OK;
+    }
     e.width = width;
     e.height = height;
+    const rsrt_status st = rsrt_environment_build_alias(ctx, slot, nullptr, 0, nullptr); // AliasTable::build_by_luminance on the device
+    if (st) { e.width = e.height = 0; }
+    return st;
+}
+
+// AliasTable::build_by_luminance (environments.rs:96-187) for the texels ALREADY in `slot`, on the device
+// (rt_alias_device.h): same bits as the host builder rsrt_alias_table_build.  Replaces the slot's alias table.
+rsrt_status rsrt_environment_build_alias(rsrt_context *ctx, uint32_t slot, rsrt_alias_entry *host_out, size_t n_entries, uint32_t *leftover_out)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    if (slot >= ctx->envs.size() || !ctx->envs[slot].rgba || !ctx->envs[slot].alias || ctx->envs[slot].width == 0)
+        return fail(ctx, RSRT_ERR_NOT_READY, "environment %u not uploaded", slot);
+    Env &e = ctx->envs[slot];
+    const size_t n = (size_t)e.width * e.height;
+    if (host_out && n_entries != n) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "build_alias: expected %zu entries", n);
+    const uint32_t nb = (uint32_t)((n + 255) / 256);
+    // scratch: p[n] | small[n] | large[n] | block counts[nb] | {sum, n_small, leftover}
+    const size_t bytes = n * 4 * 3 + (size_t)nb * 4 + 16;
+    rsrt_status st = ensure_scratch(ctx, bytes);
+    if (st || (st = begin_work(ctx, ctx->stream))) return st;
+    float *p = static_cast<float *>(ctx->scratch);
+    uint32_t *small = reinterpret_cast<uint32_t *>(p + n), *large = small + n, *blocks = large + n, *scalars = blocks + nb;
+    hipStream_t q = ctx->stream;
+    hipLaunchKernelGGL(rt_alias_weights_kernel, dim3(nb), dim3(256), 0, q, e.rgba, e.width, e.height, p);
+    hipLaunchKernelGGL(rt_alias_sum_kernel, dim3(1), dim3(64), 0, q, p, n, reinterpret_cast<float *>(scalars));
+    hipLaunchKernelGGL(rt_alias_normalise_kernel, dim3(nb), dim3(256), 0, q, p, n, reinterpret_cast<const float *>(scalars), e.alias, blocks);
+    hipLaunchKernelGGL(rt_alias_scan_kernel, dim3(1), dim3(1024), 0, q, blocks, nb, scalars + 1);
+    hipLaunchKernelGGL(rt_alias_scatter_kernel, dim3(nb), dim3(256), 0, q, p, n, blocks, small, large);
+    hipLaunchKernelGGL(rt_alias_vose_kernel, dim3(1), dim3(64), 0, q, p, n, small, scalars + 1, large, e.alias, scalars + 2);
+    HIP_TRY(ctx, hipGetLastError());
+    uint32_t left = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&left, scalars + 2, 4, hipMemcpyDeviceToHost, q));
+    if (host_out) HIP_TRY(ctx, hipMemcpyAsync(host_out, e.alias, n * sizeof(uint4), hipMemcpyDeviceToHost, q));
+    if ((st = end_work(ctx, q))) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(q));
+    if (leftover_out) *leftover_out = left;
     return RSRT_OK;
 }
 
@@ -1213,17 +1392,20 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.sample_buf = ctx->sample_buf;
 
     const int kv = ctx->kernel_variant;
-    int sv = P.scene.lds_float4s == 0 ? 0 : (P.scene.lds_hybrid ? 2 : 1);
-    if (sv == 2 && (kv == 0 || !ctx->allow_hybrid)) { sv = 0; P.scene.lds_float4s = 0; } // the first kernel has no hybrid form
+    const int trav = select_traversal(ctx, P.scene, max_bounces);
+    int sv = P.scene.lds_float4s != 0 ? 1 : 0;
+    if (sv == 0 && kv != 0 && ctx->allow_hybrid) { // mid-size scene: what the chosen traversal's box steps touch, in LDS (the first kernel has no hybrid form)
+        const uint32_t head = trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4;
+        if (head) { sv = 2; P.scene.lds_float4s = head; P.scene.lds_hybrid = 1; P.scene.lds_src = trav == 3 ? P.scene.pnodes : P.scene.nodes; }
+    }
     const uint32_t pool = sv == 2 ? 160u : kVariantPool[kv];
     const uint32_t block = sv == 2 ? 1024u : (uint32_t)RT_BLOCK;
-    const int trav = (ctx->max_traversal >= 2 && P.scene.flat_ok && max_bounces <= RT_FLAT_MAX_BOUNCES) ? 2 : ((ctx->max_traversal >= 1 && P.scene.typed_leaves) ? 1 : 0);
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
                                 : scene_bytes + (size_t)(block / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
     const void *kfn = variant_function(kv, sv, trav);
-    int &bpc = ctx->blocks_per_cu[sv * 3 + trav][kv];
+    int &bpc = ctx->blocks_per_cu[sv * 4 + trav][kv];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, (int)block, smem);
@@ -1337,20 +1519,26 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
     DeviceGuard g(ctx->device);
     if (!ctx->scene_ready) return fail(ctx, RSRT_ERR_NOT_READY, "no scene uploaded");
     if (n == 0) return RSRT_OK;
-    if (!origins || !dirs || !out || mode > 15) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: bad arguments");
-    // mode: bit 0 = cast_ray_bvh only; bits 1-2 = traversal (0 threaded, 1 stack, 2 typed leaf loops, 3 flat); bit 3 = scene
-    // read from LDS exactly as the production kernel stages it (whole image, or nodes + escape links for mid-size scenes)
+    if (!origins || !dirs || !out || mode > 31 || ((mode >> 1) & 7u) > 4u) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: bad arguments");
+    // mode: bit 0 = cast_ray_bvh only; bits 1-3 = traversal (0 threaded, 1 stack, 2 typed leaf loops, 3 flat, 4 fixed-order);
+    // bit 4 = scene read from LDS exactly as the production kernel stages it for that traversal (whole image, or for a
+    // mid-size scene the nodes + escape links / the pre-order nodes)
     DevScene sc = ctx->scene;
-    const uint32_t sel = (mode >> 1) & 3u;
-    const int trav = sel == 0 ? 0 : (sel == 1 ? 3 : (sel == 2 ? 1 : 2));
+    const uint32_t sel = (mode >> 1) & 7u;
+    const int trav = sel == 0 ? 0 : (sel == 1 ? 4 : (sel == 2 ? 1 : (sel == 3 ? 2 : 3)));
     int sv = 0;
-    if (mode & 8u) {
-        if (sc.lds_float4s == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: this scene is not staged in LDS by the production kernel");
-        sv = sc.lds_hybrid ? 2 : 1;
+    if (mode & 16u) {
+        if (sc.lds_float4s != 0) {
+            sv = 1;
+        } else {
+            const uint32_t head = trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4;
+            if (head == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: this scene is not staged in LDS by the production kernel");
+            sv = 2; sc.lds_float4s = head; sc.lds_hybrid = 1; sc.lds_src = trav == 3 ? sc.pnodes : sc.nodes;
+        }
     } else {
         sc.lds_float4s = 0;
     }
-    if (trav == 1 && !sc.typed_leaves) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: typed leaf loops need leaves of at most 8 primitives");
+    if ((trav == 1 || trav == 3) && !sc.typed_leaves) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: typed leaf loops need leaves of at most 8 primitives");
     if (trav == 2 && (!sc.flat_ok || sv == 2)) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: the flat traversal needs a scene of at most 64 records with nested boxes");
     { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     float *d_o = nullptr, *d_d = nullptr;

@@ -62,6 +62,13 @@ struct DevScene {
     uint32_t flat_ok, n_leaves;
     uint32_t tri_mask_lo, tri_mask_hi, plane_mask_lo, plane_mask_hi; // which records are triangles / planes
     const uint32_t *flat_rank; // [8 octants][16]: byte p = position of record p in that octant's depth-first visiting order
+    // fixed-order traversal (trace_preorder): its own node array — interior {min, link when hit}{max, link when missed},
+    // leaf {min, first record | 1 << 31}{max, len | masks}, successor = next element — laid out top block first
+    // (rsrt_upload_scene); [8 octants][n_prims] visiting ranks
+    const float4 *pnodes;
+    uint32_t n_pnodes;
+    const uint32_t *prim_rank;
+    const float4 *lds_src; // what stage_scene_lds copies (lds_float4s float4s): the image, nodes | escape links, or the pre-order nodes
 };
 
 struct DevEnv {
@@ -83,6 +90,8 @@ extern __shared__ float4 rt_smem[];
 template <>
 struct SceneView<true> {
     uint32_t o_nodes, o_prims, o_esc, o_trin, o_mats, o_fbs, o_fbp, o_flat;
+    const float4 *pnodes; // (not part of the LDS image: small scenes run the flat loop, the pre-order walk is an A/B there)
+    RT_DEV float4 pnode(uint32_t i) const { return pnodes[i]; }
     RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
     RT_DEV float4 flat(uint32_t i) const { return rt_smem[o_flat + i]; }
     RT_DEV float4 prim(uint32_t i) const { return rt_smem[o_prims + i]; }
@@ -99,7 +108,8 @@ struct SceneView<true> {
 };
 template <>
 struct SceneView<false> {
-    const float4 *nodes, *prims, *tri_normals, *materials, *fb_spheres, *fb_planes, *escape, *flat_leaves;
+    const float4 *nodes, *prims, *tri_normals, *materials, *fb_spheres, *fb_planes, *escape, *flat_leaves, *pnodes;
+    RT_DEV float4 pnode(uint32_t i) const { return pnodes[i]; }
     RT_DEV float4 node(uint32_t i) const { return nodes[i]; }
     RT_DEV float4 flat(uint32_t i) const { return flat_leaves[i]; }
     RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
@@ -118,6 +128,10 @@ struct SceneView<false> {
 struct SceneViewHybrid {
     uint32_t o_nodes, o_esc;
     const float4 *prims, *tri_normals, *materials, *fb_spheres, *fb_planes;
+    const float4 *pnodes;
+    uint32_t lds_f4;
+    // (the staged head is EITHER nodes | escape links OR the top block of the fixed-order walk's nodes)
+    RT_DEV float4 pnode(uint32_t i) const { return i < lds_f4 ? rt_smem[i] : pnodes[i]; }
     RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
     RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
     RT_DEV float4 trin(uint32_t i) const { return tri_normals[i]; }
@@ -1066,13 +1080,129 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
 #undef RT_FLAT_ACCEPT
 }
 
+// ------------------------------------------------------------------ fixed-order (pre-order) traversal
+// What a ray's result depends on: WHICH nodes it visits (every node all of whose ancestors' boxes it hits — the slab
+// tests decide that, not the order), which primitives it therefore tests, and — only when two of them give the very same
+// t — which one the reference meets first.  The last is a property of the ray's sign octant alone, so it is tabulated
+// at upload: prim_rank[octant][record] = the record's position in the reference's near-child-first walk.  The winner is
+// the lexicographic minimum of (t, rank) over the tested primitives, and that no longer depends on the order they are
+// tested in.  So the walk can take the ONE order that needs no side table: the node array's own pre-order.
+//   interior node, box hit    -> its first child           } both links are IN the node record (index words of its two
+//   interior node, box missed -> its subtree's successor   } float4s), so the array can be laid out in any order:
+//   leaf                      -> the next array element     the hottest nodes first, kept in LDS (rsrt_upload_scene)
+// Two 16-byte loads per step instead of three (no escape link), no octant-dependent addressing, and for a scene of any
+// size the top of the tree — where most box tests happen — is served by LDS instead of the vector L1, which is what
+// bounds the all-global walk (profiles/r02_bvh_*); same boxes, same primitives, same winner as cast_ray_bvh
+// (shader.wgsl:469-564).
+// `ref_mem`: where the incumbent's record index lives when a resumed traversal has not loaded it (pool kernel: the
+// slot's C_REF column); read only if a primitive ties with the incumbent.  h.ref == RT_REF_UNKNOWN until then.
+#define RT_REF_UNKNOWN 0xffffffffu
+RT_DEV uint32_t prim_rank_of(const DevScene &sc, uint32_t octant, uint32_t rec) { return sc.prim_rank[(size_t)octant * sc.n_prims + rec]; }
+
+template <class View>
+RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t &cur, Hit &h,
+                           const uint32_t *ref_mem)
+{
+    static_assert(RT_LEAFQ <= 4, "one byte of each 32-bit mask per held leaf");
+    const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+    const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    const uint32_t n_elems = sc.n_pnodes;
+    uint32_t steps = 0;
+    while (cur != RT_END && steps < budget) {
+        DBG_WAVE_TICK(14);
+        uint32_t qi[RT_LEAFQ];
+        uint32_t nq = 0, all_m = 0, tri_m = 0, pl_m = 0;
+#pragma unroll
+        for (int j = 0; j < RT_LEAFQ; j++) qi[j] = 0u;
+        while (cur != RT_END && nq < RT_LEAFQ) {
+            DBG_WAVE_TICK(10);
+            DBG_ADD(11, 1);
+            steps++;
+            const float4 n0 = S.pnode(2u * cur), n1 = S.pnode(2u * cur + 1u);
+            float t_0;
+            bool inside = slab_test(n0, n1, o, inv, t_0);
+            inside = inside & !(prune & (t_0 > h.t));
+            const uint32_t w0 = as_u(n0.w), w1 = as_u(n1.w);
+            const bool leaf = (w0 >> 31) != 0u;
+            if (inside & leaf) {
+                const uint32_t idx = w0 & 0x7fffffffu, len = w1 & 0xffffu, hi = w1 >> 16; // triangle mask | plane mask << 8
+#pragma unroll
+                for (int j = 0; j < RT_LEAFQ; j++) qi[j] = (nq == (uint32_t)j) ? idx : qi[j];
+                const uint32_t sh = 8u * nq;
+                all_m |= ((1u << len) - 1u) << sh;
+                tri_m |= (hi & 0xffu) << sh;
+                pl_m |= (hi >> 8) << sh;
+                steps += len;
+                nq++;
+            }
+            // leaf: the next element; interior: first child when hit, the subtree's successor when missed (a jump
+            // element has both links equal, so its never-valid box does not matter)
+            const uint32_t next = leaf ? cur + 1u : (inside ? w0 : w1);
+            cur = next >= n_elems ? RT_END : next;
+        }
+        uint32_t sp_m = all_m & ~(tri_m | pl_m);
+        // equal t: the record the reference meets first wins (rare: coincident geometry)
+#define RT_PRE_ACCEPT(t, rec)                                                                                   \
+        bool better = ((t) >= 0.0f) & ((t) < h.t);                                                                  \
+        if (((t) == h.t) & (h.t < RT_INFINITY)) {                                                                   \
+            if (h.ref == RT_REF_UNKNOWN) h.ref = *ref_mem;                                                          \
+            better = prim_rank_of(sc, octant, (rec)) < prim_rank_of(sc, octant, h.ref);                            \
+        }                                                                                                           \
+        h.t = better ? (t) : h.t;                                                                                   \
+        h.ref = better ? (rec) : h.ref;
+        while (tri_m != 0u) {
+            DBG_WAVE_TICK(12);
+            DBG_ADD(13, 1);
+            const uint32_t p = take_lowest(tri_m);
+            uint32_t base = qi[0];
+#pragma unroll
+            for (int j = 1; j < RT_LEAFQ; j++) base = ((p >> 3) == (uint32_t)j) ? qi[j] : base;
+            const uint32_t rec = base + (p & 7u);
+            const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u);
+            float u, v;
+            const float t = triangle_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), u, v);
+            RT_PRE_ACCEPT(t, rec)
+            if (better & anyhit) { cur = RT_END; tri_m = pl_m = sp_m = 0u; }
+        }
+        while (pl_m != 0u) {
+            DBG_WAVE_TICK(15);
+            DBG_ADD(13, 1);
+            const uint32_t p = take_lowest(pl_m);
+            uint32_t base = qi[0];
+#pragma unroll
+            for (int j = 1; j < RT_LEAFQ; j++) base = ((p >> 3) == (uint32_t)j) ? qi[j] : base;
+            const uint32_t rec = base + (p & 7u);
+            const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u), r3 = S.prim(4u * rec + 3u);
+            const float t = plane_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), v3(r3.x, r3.y, r3.z));
+            RT_PRE_ACCEPT(t, rec)
+            if (better & anyhit) { cur = RT_END; pl_m = sp_m = 0u; }
+        }
+        while (sp_m != 0u) {
+            DBG_WAVE_TICK(28);
+            DBG_ADD(13, 1);
+            const uint32_t p = take_lowest(sp_m);
+            uint32_t base = qi[0];
+#pragma unroll
+            for (int j = 1; j < RT_LEAFQ; j++) base = ((p >> 3) == (uint32_t)j) ? qi[j] : base;
+            const uint32_t rec = base + (p & 7u);
+            const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u);
+            const float t = sphere_t(o, d, v3(r0.x, r0.y, r0.z), r1.y);
+            RT_PRE_ACCEPT(t, rec)
+            if (better & anyhit) { cur = RT_END; sp_m = 0u; }
+        }
+#undef RT_PRE_ACCEPT
+    }
+}
+
 // ------------------------------------------------------------------ which traversal runs
 // TRAV: 0 trace_threaded (any BVH), 1 trace_threaded_typed (no leaf longer than 8 primitives), 2 trace_flat (<= 64
-// records, nested boxes).  One function so that the production kernel's TRACE stage and the ray-query probe
-// (rsrt_cast_rays) run the very same code.  `cur` is the traversal cursor (0 = start at the root, RT_END = done),
-// `h` the best hit so far; the tree walks stop after ~`budget` steps and are resumed by calling again.
+// records, nested boxes), 3 trace_preorder (no leaf longer than 8 primitives).  One function so that the production
+// kernel's TRACE stage and the ray-query probe (rsrt_cast_rays) run the very same code.  `cur` is the traversal cursor
+// (0 = start at the root, RT_END = done), `h` the best hit so far; the tree walks stop after ~`budget` steps and are
+// resumed by calling again.  `ref_mem`: see trace_preorder.
 template <int TRAV, class View>
-RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t &cur, Hit &h)
+RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t &cur, Hit &h,
+                           const uint32_t *ref_mem)
 {
     if (TRAV == 2) {
         const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
@@ -1084,6 +1214,8 @@ RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
         } else {
             trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, 0xffffffffu, cur, h);
         }
+    } else if (TRAV == 3) {
+        trace_preorder(DBG_ARG S, sc, o, d, prune, anyhit, budget, cur, h, ref_mem);
     } else if (TRAV == 1) {
         trace_threaded_typed(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, budget, cur, h);
     } else {

@@ -112,7 +112,8 @@ RT_DEV void store_sample(float *dst, V3 L)
 #define RT_POOL_WAVES_PER_SIMD 4
 #endif
 // TRAV: which traversal TRACE runs — 0 trace_threaded (any BVH), 1 trace_threaded_typed (leaves of <= 8
-// primitives), 2 trace_flat (<= 64 primitive records, nested boxes; rays with a non-finite 1/d fall back to 0)
+// primitives), 2 trace_flat (<= 64 primitive records, nested boxes; rays with a non-finite 1/d fall back to 0),
+// 3 trace_preorder (leaves of <= 8 primitives; fixed order, ties by tabulated visiting rank)
 // SV: where the scene is read from — 0 global memory, 1 the whole image in LDS (256-thread workgroups, several per
 // CU), 2 nodes + escape links in LDS (SceneViewHybrid; BLOCK = 1024: one workgroup per CU shares the copy)
 template <int SV> struct PoolView;
@@ -262,13 +263,17 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 Hit h;
                 uint32_t cur = kBounceInCt ? 0u : (ct >> CT_SHIFT); // (flat: every ray finishes in one call, the bits carry the bounce count)
                 h.src = SRC_BVH;
-                h.t = HOTF(H_T, slot); h.ref = 0; h.u = h.v = 0.0f; // ref of an earlier call stays in the cold column unless beaten
+                h.t = HOTF(H_T, slot); h.u = h.v = 0.0f;
+                // the record of an earlier call's best hit stays in the cold column unless beaten; the fixed-order walk, where
+                // an equal t can still replace it, fetches it from there if (and only if) such a tie comes up
+                h.ref = (TRAV == 3 && !shadow) ? RT_REF_UNKNOWN : 0u;
                 const float t_in = h.t;
-                trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h);
+                trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h, &COLD(C_REF, slot));
+                const bool found = TRAV == 3 ? (h.ref != RT_REF_UNKNOWN) : (h.t < t_in); // this call found a closer (or earlier-ranked) hit
                 const bool done = cur == RT_END;
                 if (!done) { // to be resumed: best t and cursor
                     SETH(H_T, slot, h.t);
-                    if (TRAV != 2 && !shadow && h.t < t_in) COLD(C_REF, slot) = h.ref;
+                    if (TRAV != 2 && !shadow && found) COLD(C_REF, slot) = h.ref;
                     SET_CT(slot, cur, ct & CT_FLAGS, TAG_TRACE);
                 } else if (shadow) {
                     n_shadow++;
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 } else {
                     n_ext++;
                     SETH(H_T, slot, h.t);
-                    if (TRAV != 2 && h.t < t_in) COLD(C_REF, slot) = h.ref; // this call found a closer hit
+                    if (TRAV != 2 && found) COLD(C_REF, slot) = h.ref;
                     // the flat traversal's records fit the idle cursor bits: no cold column
                     SET_CT(slot, (TRAV == 2 ? h.ref : 0u) | (kBounceInCt ? (ct >> CT_SHIFT) : 0u), ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
                 }

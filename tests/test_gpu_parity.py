@@ -57,10 +57,11 @@ def test_matches_golden_images_bit_exact(name):
 
 def probe_modes(name):
     """Every way rsrt_cast_rays can run a query (include/rsrt.h): traversal 0 threaded / 1 stack / 2 typed leaf loops /
-    3 flat (what house, default and cube run in production; suzanne's 968 triangles do not qualify), x scene read from
-    global memory or from LDS as the production kernel stages it (bit 3), x cast_ray / cast_ray_bvh (bit 0)."""
-    sels = [0, 1, 2] + ([3] if name != "suzanne" else [])
-    return [(sel << 1) | lds | bvh_only for sel in sels for lds in (0, 8) for bvh_only in (0, 1)]
+    3 flat (what house, default and cube run in production; suzanne's 968 triangles do not qualify) / 4 fixed-order walk
+    (what suzanne and anything bigger run), x scene read from global memory or from LDS as the production kernel stages
+    it for that traversal (bit 4), x cast_ray / cast_ray_bvh (bit 0)."""
+    sels = [0, 1, 2, 4] + ([3] if name != "suzanne" else [])
+    return [(sel << 1) | lds | bvh_only for sel in sels for lds in (0, 16) for bvh_only in (0, 1)]
 
 
 @pytest.mark.parametrize("name", SCENES)
@@ -82,7 +83,9 @@ def test_probe_refuses_a_traversal_the_scene_does_not_qualify_for():
     with pytest.raises(R.RsrtError, match="flat traversal"):
         st.cast_rays(o, d, 3 << 1, 0)
     with pytest.raises(R.RsrtError, match="bad arguments"):
-        st.cast_rays(o, d, 16, 0)
+        st.cast_rays(o, d, 32, 0)
+    with pytest.raises(R.RsrtError, match="bad arguments"):
+        st.cast_rays(o, d, 5 << 1, 0)
     st.close()
 
 
@@ -98,13 +101,16 @@ def test_matches_oracle_live(name, w, h, spp, mb, big_env):
     assert (st["paths"], st["ext_rays"], st["shadow_rays"]) == (ost["paths"], ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("variant,traversal", [("0", "2"), ("1", "2"), ("2", "2"), ("2", "1"), ("2", "0")])
+@pytest.mark.parametrize("variant,traversal", [("0", "3"), ("1", "3"), ("2", "3"), ("3", "3"), ("2", "3-noflat"), ("2", "1"), ("2", "0")])
 def test_every_kernel_variant_is_bit_exact(variant, traversal, big_env, monkeypatch):
-    """RSRT_KERNEL: 0 = lockstep megakernel, 1/2 = stage-scheduled wave-pool kernel (192/160 slots per wave);
-    RSRT_TRAVERSAL caps the traversal: 2 flat small-scene loop, 1 tree walk with per-type leaf loops, 0 generic tree walk.
+    """RSRT_KERNEL: 0 = lockstep megakernel, 1/2/3 = stage-scheduled wave-pool kernel (192/160/128 slots per wave);
+    RSRT_TRAVERSAL caps the traversal: 3 = product (flat loop for small scenes, fixed-order walk otherwise; with
+    RSRT_FLAT=0 the fixed-order walk for small scenes too), 1 tree walk with per-type leaf loops, 0 generic tree walk.
     Scheduling differs, the per-path arithmetic does not: all must give the oracle's bits."""
     monkeypatch.setenv("RSRT_KERNEL", variant)
-    monkeypatch.setenv("RSRT_TRAVERSAL", traversal)
+    monkeypatch.setenv("RSRT_TRAVERSAL", traversal[0])
+    if traversal.endswith("noflat"):
+        monkeypatch.setenv("RSRT_FLAT", "0")
     for name, w, h, spp, mb in [("house", 150, 70, 6, 8), ("suzanne", 64, 48, 3, 10)]:
         sc = R.Scene.load_toml(util.scene_path(name))
         ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), w, h, 0, spp, mb)
@@ -495,15 +501,20 @@ def test_leaves_that_share_records_or_too_many_fallback_records_keep_the_tree_wa
     assert (st2["ext_rays"], st2["shadow_rays"]) == (ost2["ext_rays"], ost2["shadow_rays"])
 
 
-@pytest.mark.parametrize("traversal", ["2", "1", "0"])
+@pytest.mark.parametrize("traversal", ["3", "3-noflat", "1", "0"])
 def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_env, monkeypatch):
     """Every primitive exists three times, at the same place, with three different materials, so every hit is a
     tie of equal t between records that usually sit in different leaves.  The reference keeps the first one it
     visits (strict `<`, near-child-first order, which depends on the ray's sign octant); the material of the
-    winner is visible in the picture.  Exercises the visiting-order ranks of the flat traversal and the position
-    rule of the typed leaf loops."""
+    winner is visible in the picture.  Exercises the visiting-order ranks of the flat traversal ("3": this scene has
+    27 records) and of the fixed-order walk ("3-noflat"), and the position rule of the typed leaf loops; with a
+    TRACE budget of 3 steps every traversal is cut and resumed many times, ties against an incumbent of an earlier
+    call included."""
     from rsoderh_raytracing_amd import host, types as T
-    monkeypatch.setenv("RSRT_TRAVERSAL", traversal)
+    monkeypatch.setenv("RSRT_TRAVERSAL", traversal[0])
+    monkeypatch.setenv("RSRT_TRACE_BUDGET", "3")
+    if traversal.endswith("noflat"):
+        monkeypatch.setenv("RSRT_FLAT", "0")
     rng = np.random.default_rng(23)
     mats = np.zeros(3, T.MATERIAL)
     mats["color"] = [[0.9, 0.1, 0.1], [0.1, 0.9, 0.1], [0.1, 0.1, 0.9]]
@@ -538,13 +549,40 @@ def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_en
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("hybrid", ["1", "0"])
-def test_mid_size_scene_with_nodes_in_lds_or_in_global_memory(hybrid, big_env, monkeypatch):
-    """suzanne (968 triangles): too big for the LDS image; by default its nodes and escape links are staged in LDS
-    for one 1024-thread workgroup per CU (RSRT_HYBRID=0: everything from global memory).  Same bits either way."""
+@pytest.mark.parametrize("hybrid,traversal", [("1", "3"), ("0", "3"), ("1", "1"), ("0", "1")])
+def test_mid_size_scene_with_nodes_in_lds_or_in_global_memory(hybrid, traversal, big_env, monkeypatch):
+    """suzanne (968 triangles): too big for the LDS image; by default what its box steps touch — the pre-order nodes of
+    the fixed-order walk, or the nodes and escape links of the tree walk (RSRT_TRAVERSAL=1) — is staged in LDS for one
+    1024-thread workgroup per CU (RSRT_HYBRID=0: everything from global memory).  Same bits every way."""
     monkeypatch.setenv("RSRT_HYBRID", hybrid)
+    monkeypatch.setenv("RSRT_TRAVERSAL", traversal)
     sc = R.Scene.load_toml(util.scene_path("suzanne"))
     ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 120, 68, 0, 4, 10)
     img, st = gpu_render(sc, big_env, 120, 68, 0, 4, 10)
     assert np.array_equal(util.bits(img), util.bits(ref))
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+
+
+def test_big_scene_all_global_is_bit_exact(big_env):
+    """The builder-authored suzanne grid (tools/make_big_scene.py: 15,488 triangles, ~8.7 k nodes): nothing of it fits
+    the LDS budget, so the fixed-order walk reads nodes and records from global memory.  Reduced size, bit for bit."""
+    import sys
+    sys.path.insert(0, util.ROOT + "/tools")
+    import make_big_scene
+    sc = R.Scene.load_toml(make_big_scene.make(4))
+    assert len(sc.triangles) == 15488 and len(sc.bvh_nodes) > 8000
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 200, 112, 0, 3, 10, fast=True)
+    img, st = gpu_render(sc, big_env, 200, 112, 0, 3, 10)
+    assert np.array_equal(util.bits(img), util.bits(ref))
+    assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+    # the ray probe on the same scene: fixed-order walk and tree walks agree with the oracle's cast_ray
+    rng = np.random.default_rng(5)
+    o = rng.uniform(-6, 6, (4096, 3)).astype(np.float32) + np.float32([0, 2, 2])
+    d = rng.normal(size=(4096, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    hits = oracle.cast_rays(util.oracle_scene(sc), o, d, 0, 0)
+    s2 = R.State.new(sc, util.small_env(), 16, 16)
+    for mode in (0 << 1, 2 << 1, 4 << 1):
+        got = s2.cast_rays(o, d, mode, 0)
+        assert np.array_equal(np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9), hits.view(np.uint32).reshape(-1, 9)), mode
+    s2.close()
