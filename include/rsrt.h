@@ -82,6 +82,8 @@ typedef struct rsrt_stats {
     double trace_kernel_ms;   /* part of kernel_ms spent in the path-tracing kernel (rt_render_kernel) */
     double resolve_kernel_ms; /* part spent in the ordered sample resolve (rt_resolve_kernel) */
     double reduce_ms;         /* HIP-event time of rsrt_comm_reduce calls (the RCCL reduce of the accumulators) */
+    uint64_t traversal_steps; /* box tests + primitive tests of the BVH walks (0 where the flat small-scene loop runs:
+                                 its work per ray is fixed by the scene); what RSRT_FLAG_PRUNE reduces */
 } rsrt_stats;
 
 /* -- context: State::new's device acquisition (state.rs:60-98) ------------------------------ */

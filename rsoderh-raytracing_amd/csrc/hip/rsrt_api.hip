@@ -29,7 +29,7 @@
 #include "rt_device.h"
 
 #define RT_BLOCK 256
-#define RT_STATS_WORDS 40 // paths, ext, shadow + 32 diagnostic words (zero in the product build)
+#define RT_STATS_WORDS 40 // paths, ext, shadow, traversal steps + 32 diagnostic words (zero in the product build)
 #define RT_WAVE 64
 
 struct RenderParams {
@@ -45,7 +45,7 @@ struct RenderParams {
     uint32_t samples_per_chunk, n_sblocks, n_chunks;
     uint32_t chunk_px, n_subtiles; // a chunk covers chunk_px consecutive pixels of a tile (tile_px / n_subtiles)
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
-    uint32_t trace_budget;
+    uint32_t trace_budget, descend_quorum;
     uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
     float *sample_buf;
     unsigned int *work_counter;
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
 #ifdef RT_INSTRUMENT
         DbgCounters dbg;
 #endif
-        uint32_t cur = 0;
-        while (cur != RT_END) trace_dispatch<(TRAV == 4 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, cur, h, nullptr);
+        uint32_t cur = 0, work = 0;
+        while (cur != RT_END) trace_dispatch<(TRAV == 4 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, 50u, cur, h, nullptr, work);
         if (h.did_hit()) hit_barycentrics(S, h, o, d); // as SHADE does: the traversals do not carry u, v
     }
     if ((mode & 1u) == 0 && !h.did_hit()) { // cast_ray's brute-force fallback (the MISS stage)
@@ -462,7 +462,7 @@ struct rsrt_context {
     struct PassEvents { hipEvent_t begin, traced, end; };
     std::vector<PassEvents> pending_events;
     double cum_trace_ms = 0, cum_resolve_ms = 0, base_trace_ms = 0, base_resolve_ms = 0;
-    unsigned long long base_counts[3] = {0, 0, 0};
+    unsigned long long base_counts[4] = {0, 0, 0, 0};
     uint32_t cum_launches = 0, base_launches = 0;
     std::vector<hipEvent_t> event_pool;
     // Work buffers (work_counter, sample_buf, cold_state, scratch) and the accumulator are per-context
@@ -487,7 +487,8 @@ struct rsrt_context {
     int max_traversal = 3; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
     bool allow_flat = true;
     bool allow_hybrid = true;
-    uint32_t trace_budget = 12; // traversal steps per TRACE invocation before a ray is re-queued
+    uint32_t trace_budget = 0; // traversal steps per TRACE invocation before a ray is re-queued (0: 6 for the fixed-order walk, 12 for the tree walks)
+    uint32_t descend_quorum = 30; // fixed-order walk: a descending round ends once fewer than this percentage of its lanes are still descending
     unsigned long long debug_words[32] = {0};
 };
 
@@ -660,6 +661,7 @@ rsrt_status collect_stats(rsrt_context *ctx)
     s.paths = c[0] - ctx->base_counts[0];
     s.ext_rays = c[1] - ctx->base_counts[1];
     s.shadow_rays = c[2] - ctx->base_counts[2];
+    s.traversal_steps = c[3] - ctx->base_counts[3];
     s.trace_kernel_ms = ctx->cum_trace_ms - ctx->base_trace_ms;
     s.resolve_kernel_ms = ctx->cum_resolve_ms - ctx->base_resolve_ms;
     s.kernel_ms = s.trace_kernel_ms + s.resolve_kernel_ms;
@@ -670,11 +672,11 @@ rsrt_status collect_stats(rsrt_context *ctx)
     s.total_kernel_ms = ctx->cum_trace_ms + ctx->cum_resolve_ms;
     s.reduce_ms = ctx->cum_reduce_ms - ctx->base_reduce_ms;
     ctx->base_reduce_ms = ctx->cum_reduce_ms;
-    for (int i = 0; i < 3; i++) ctx->base_counts[i] = c[i];
+    for (int i = 0; i < 4; i++) ctx->base_counts[i] = c[i];
     ctx->base_trace_ms = ctx->cum_trace_ms;
     ctx->base_resolve_ms = ctx->cum_resolve_ms;
     ctx->base_launches = ctx->cum_launches;
-    memcpy(ctx->debug_words, c + 3, sizeof ctx->debug_words);
+    memcpy(ctx->debug_words, c + 4, sizeof ctx->debug_words);
     return RSRT_OK;
 }
 
@@ -795,6 +797,7 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     if (const char *ty = getenv("RSRT_TRAVERSAL")) ctx->max_traversal = atoi(ty); // cap: 0 generic tree walk, 1 typed leaf loops, 2 + flat small-scene loop, 3 + fixed-order walk (A/B)
     if (const char *fl = getenv("RSRT_FLAT")) ctx->allow_flat = atoi(fl) != 0; // 0: small scenes take the walk a big scene would (A/B)
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
+    if (const char *dq = getenv("RSRT_DESCEND_QUORUM")) { int v = atoi(dq); if (v >= 0 && v <= 100) ctx->descend_quorum = (uint32_t)v; }
     for (int m = 0; m < 15; m++) (void)hipFuncSetAttribute(probe_function(m / 5, m % 5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
     snprintf(buf, sizeof buf, "librsrt 0.1; %s (%s); %d CUs", prop.name, prop.gcnArchName, ctx->cus);
@@ -1372,7 +1375,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     if ((uint64_t)P.n_owned_tiles * tile_px > 0x7fffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "frame too large");
     P.n_slots = P.n_owned_tiles * tile_px;
     P.work_counter = ctx->work_counter;
-    P.trace_budget = ctx->trace_budget;
+    P.descend_quorum = ctx->descend_quorum;
     P.stats = ctx->dev_stats;
     if (P.n_slots == 0) return RSRT_OK;
 
@@ -1398,6 +1401,9 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         const uint32_t head = trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4;
         if (head) { sv = 2; P.scene.lds_float4s = head; P.scene.lds_hybrid = 1; P.scene.lds_src = trav == 3 ? P.scene.pnodes : P.scene.nodes; }
     }
+    // measured on suzanne and the 15 k-triangle grid (profiles/r02_bvh_knobs.txt): with the quorum vote a round is short, and
+    // handing the slot back to the scheduler after about one round beats running several rounds with thinning lanes
+    P.trace_budget = ctx->trace_budget ? ctx->trace_budget : (trav == 3 ? 6u : 12u);
     const uint32_t pool = sv == 2 ? 160u : kVariantPool[kv];
     const uint32_t block = sv == 2 ? 1024u : (uint32_t)RT_BLOCK;
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);

@@ -382,7 +382,7 @@ rsrt_status rsrt_multi_get_stats(rsrt_multi *m, rsrt_stats *out)
         rsrt_stats s;
         const rsrt_status st = rsrt_get_stats(c, &s);
         if (st) return st;
-        out->paths += s.paths; out->ext_rays += s.ext_rays; out->shadow_rays += s.shadow_rays;
+        out->paths += s.paths; out->ext_rays += s.ext_rays; out->shadow_rays += s.shadow_rays; out->traversal_steps += s.traversal_steps;
         out->total_paths += s.total_paths; out->total_ext_rays += s.total_ext_rays; out->total_shadow_rays += s.total_shadow_rays;
         out->launches += s.launches;
         out->kernel_ms = std::max(out->kernel_ms, s.kernel_ms);

@@ -91,7 +91,7 @@ template <>
 struct SceneView<true> {
     uint32_t o_nodes, o_prims, o_esc, o_trin, o_mats, o_fbs, o_fbp, o_flat;
     const float4 *pnodes; // (not part of the LDS image: small scenes run the flat loop, the pre-order walk is an A/B there)
-    RT_DEV float4 pnode(uint32_t i) const { return pnodes[i]; }
+    RT_DEV void pnode_pair(uint32_t e, float4 &n0, float4 &n1) const { n0 = pnodes[2u * e]; n1 = pnodes[2u * e + 1u]; }
     RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
     RT_DEV float4 flat(uint32_t i) const { return rt_smem[o_flat + i]; }
     RT_DEV float4 prim(uint32_t i) const { return rt_smem[o_prims + i]; }
@@ -109,7 +109,7 @@ struct SceneView<true> {
 template <>
 struct SceneView<false> {
     const float4 *nodes, *prims, *tri_normals, *materials, *fb_spheres, *fb_planes, *escape, *flat_leaves, *pnodes;
-    RT_DEV float4 pnode(uint32_t i) const { return pnodes[i]; }
+    RT_DEV void pnode_pair(uint32_t e, float4 &n0, float4 &n1) const { n0 = pnodes[2u * e]; n1 = pnodes[2u * e + 1u]; }
     RT_DEV float4 node(uint32_t i) const { return nodes[i]; }
     RT_DEV float4 flat(uint32_t i) const { return flat_leaves[i]; }
     RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
@@ -131,7 +131,32 @@ struct SceneViewHybrid {
     const float4 *pnodes;
     uint32_t lds_f4;
     // (the staged head is EITHER nodes | escape links OR the top block of the fixed-order walk's nodes)
-    RT_DEV float4 pnode(uint32_t i) const { return i < lds_f4 ? rt_smem[i] : pnodes[i]; }
+    // Element e of the fixed-order walk: from LDS when it is in the top block, else from global memory.  Written as an
+    // unconditional ds_read (of element 0 for the lanes that are past the block) plus a global load under a branch:
+    // a select between the two POINTERS makes the compiler emit flat loads, which take the texture path even for LDS
+    // and are waited for one by one (measured: the walk ran 12 % slower than with three loads per step).
+    RT_DEV void pnode_pair(uint32_t e, float4 &n0, float4 &n1) const
+    {
+        const bool in_lds = 2u * e < lds_f4;
+        const uint32_t k = in_lds ? 2u * e : 0u;
+#if RT_PNODE_GLOBAL_FIRST // A/B: global loads issued before the LDS reads, results selected (8 more v_cndmask, no LDS wait in front of the global loads)
+        float4 g0 = float4{0, 0, 0, 0}, g1 = g0;
+        if (!in_lds) {
+            g0 = pnodes[2u * e];
+            g1 = pnodes[2u * e + 1u];
+        }
+        const float4 l0 = rt_smem[k], l1 = rt_smem[k + 1u];
+        n0 = float4{in_lds ? l0.x : g0.x, in_lds ? l0.y : g0.y, in_lds ? l0.z : g0.z, in_lds ? l0.w : g0.w};
+        n1 = float4{in_lds ? l1.x : g1.x, in_lds ? l1.y : g1.y, in_lds ? l1.z : g1.z, in_lds ? l1.w : g1.w};
+#else
+        n0 = rt_smem[k];
+        n1 = rt_smem[k + 1u];
+        if (!in_lds) {
+            n0 = pnodes[2u * e];
+            n1 = pnodes[2u * e + 1u];
+        }
+#endif
+    }
     RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
     RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
     RT_DEV float4 trin(uint32_t i) const { return tri_normals[i]; }
@@ -418,6 +443,9 @@ RT_DEV float environment_pixel_solid_angle(float v, const DevEnv &e) // :739-749
 // ~90 % of the picks) stay cacheable.  A/B of what the stream does to the L2 share of the path-state arena.
 #ifndef RT_ENV_NT
 #define RT_ENV_NT 0
+#endif
+#ifndef RT_PNODE_GLOBAL_FIRST
+#define RT_PNODE_GLOBAL_FIRST 0
 #endif
 typedef float rt_f4v __attribute__((ext_vector_type(4)));
 typedef uint32_t rt_u4v __attribute__((ext_vector_type(4)));
@@ -817,7 +845,7 @@ RT_DEV bool slab_test(float4 n0, float4 n1, V3 o, V3 inv, float &t_entry)
 // against a slightly older best t.)
 template <class View>
 RT_DEV void trace_threaded(DBG_DECL const View &S, uint32_t n_nodes, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget,
-                           uint32_t &cur, Hit &h)
+                           uint32_t &cur, Hit &h, uint32_t &work)
 {
     const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
     const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
@@ -882,6 +910,7 @@ RT_DEV void trace_threaded(DBG_DECL const View &S, uint32_t n_nodes, V3 o, V3 d,
             }
         }
     }
+    work += steps; // box steps + primitive tests: rsrt_stats.traversal_steps
 }
 
 // ------------------------------------------------------------------ typed leaf loops
@@ -904,7 +933,7 @@ RT_DEV uint32_t take_lowest(uint32_t &mask)
 
 template <class View>
 RT_DEV void trace_threaded_typed(DBG_DECL const View &S, uint32_t n_nodes, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t &cur,
-                                 Hit &h)
+                                 Hit &h, uint32_t &work)
 {
     static_assert(RT_LEAFQ <= 4, "one byte of each 32-bit mask per held leaf");
     const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
@@ -996,6 +1025,7 @@ RT_DEV void trace_threaded_typed(DBG_DECL const View &S, uint32_t n_nodes, V3 o,
             if (better & anyhit) { cur = RT_END; sp_m = 0u; }
         }
     }
+    work += steps;
 }
 
 // ------------------------------------------------------------------ flat traversal of small scenes
@@ -1100,8 +1130,8 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
 RT_DEV uint32_t prim_rank_of(const DevScene &sc, uint32_t octant, uint32_t rec) { return sc.prim_rank[(size_t)octant * sc.n_prims + rec]; }
 
 template <class View>
-RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t &cur, Hit &h,
-                           const uint32_t *ref_mem)
+RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t quorum, uint32_t &cur,
+                           Hit &h, const uint32_t *ref_mem, uint32_t &work)
 {
     static_assert(RT_LEAFQ <= 4, "one byte of each 32-bit mask per held leaf");
     const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
@@ -1114,11 +1144,18 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
         uint32_t nq = 0, all_m = 0, tri_m = 0, pl_m = 0;
 #pragma unroll
         for (int j = 0; j < RT_LEAFQ; j++) qi[j] = 0u;
+        // Lanes descend until they hold RT_LEAFQ leaves — but not for ever: rays need very different numbers of box steps
+        // to get there (suzanne grid: 22 on average, 60 for the slowest lane of a wave), and every lane that is done
+        // idles until the last one is.  So the wave takes a vote each trip and stops descending once fewer than
+        // `quorum` percent of the lanes that started the round are still at it; whatever leaves are held are tested, and
+        // the stragglers descend on in the next round TOGETHER with everyone else (the cursor is all the state there is).
+        const uint32_t started = (uint32_t)__popcll(__ballot(true));
         while (cur != RT_END && nq < RT_LEAFQ) {
             DBG_WAVE_TICK(10);
             DBG_ADD(11, 1);
             steps++;
-            const float4 n0 = S.pnode(2u * cur), n1 = S.pnode(2u * cur + 1u);
+            float4 n0, n1;
+            S.pnode_pair(cur, n0, n1);
             float t_0;
             bool inside = slab_test(n0, n1, o, inv, t_0);
             inside = inside & !(prune & (t_0 > h.t));
@@ -1139,6 +1176,7 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
             // element has both links equal, so its never-valid box does not matter)
             const uint32_t next = leaf ? cur + 1u : (inside ? w0 : w1);
             cur = next >= n_elems ? RT_END : next;
+            if ((uint32_t)__popcll(__ballot((cur != RT_END) & (nq < RT_LEAFQ))) * 100u < started * quorum) break; // wave-uniform
         }
         uint32_t sp_m = all_m & ~(tri_m | pl_m);
         // equal t: the record the reference meets first wins (rare: coincident geometry)
@@ -1192,6 +1230,7 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
         }
 #undef RT_PRE_ACCEPT
     }
+    work += steps;
 }
 
 // ------------------------------------------------------------------ which traversal runs
@@ -1199,10 +1238,11 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
 // records, nested boxes), 3 trace_preorder (no leaf longer than 8 primitives).  One function so that the production
 // kernel's TRACE stage and the ray-query probe (rsrt_cast_rays) run the very same code.  `cur` is the traversal cursor
 // (0 = start at the root, RT_END = done), `h` the best hit so far; the tree walks stop after ~`budget` steps and are
-// resumed by calling again.  `ref_mem`: see trace_preorder.
+// resumed by calling again.  `ref_mem`: see trace_preorder.  `work` += box steps + primitive tests of the tree walks
+// (the flat loop, whose work per ray is fixed by the scene, adds nothing).
 template <int TRAV, class View>
-RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t &cur, Hit &h,
-                           const uint32_t *ref_mem)
+RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t quorum, uint32_t &cur,
+                           Hit &h, const uint32_t *ref_mem, uint32_t &work)
 {
     if (TRAV == 2) {
         const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
@@ -1212,13 +1252,13 @@ RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
             trace_flat(DBG_ARG S, sc, o, d, inv, anyhit, h);
             cur = RT_END;
         } else {
-            trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, 0xffffffffu, cur, h);
+            trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, 0xffffffffu, cur, h, work);
         }
     } else if (TRAV == 3) {
-        trace_preorder(DBG_ARG S, sc, o, d, prune, anyhit, budget, cur, h, ref_mem);
+        trace_preorder(DBG_ARG S, sc, o, d, prune, anyhit, budget, quorum, cur, h, ref_mem, work);
     } else if (TRAV == 1) {
-        trace_threaded_typed(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, budget, cur, h);
+        trace_threaded_typed(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, budget, cur, h, work);
     } else {
-        trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, budget, cur, h);
+        trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, budget, cur, h, work);
     }
 }

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     uint32_t chunk_next = 0, chunk_left = 0, chunk_tile_slot0 = 0, chunk_tx0 = 0, chunk_ty0 = 0, chunk_s0 = 0, chunk_p0 = 0;
     bool exhausted = false;
     unsigned long long n_paths = 0, n_ext = 0, n_shadow = 0;
+    uint32_t n_work = 0; // box steps + primitive tests of the tree walks (per lane; widened in the final reduction)
 #ifdef RT_INSTRUMENT
     DbgCounters dbg;
     for (int i = 0; i < RT_DBG_N; i++) dbg.c[i] = 0;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 // an equal t can still replace it, fetches it from there if (and only if) such a tie comes up
                 h.ref = (TRAV == 3 && !shadow) ? RT_REF_UNKNOWN : 0u;
                 const float t_in = h.t;
-                trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, cur, h, &COLD(C_REF, slot));
+                trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, P.descend_quorum, cur, h, &COLD(C_REF, slot), n_work);
                 const bool found = TRAV == 3 ? (h.ref != RT_REF_UNKNOWN) : (h.t < t_in); // this call found a closer (or earlier-ranked) hit
                 const bool done = cur == RT_END;
                 if (!done) { // to be resumed: best t and cursor
@@ -424,21 +425,24 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
 #undef COLDF
 #undef SETC
 
+    unsigned long long n_work64 = n_work;
     for (int off = 32; off > 0; off >>= 1) {
         n_paths += __shfl_down(n_paths, off);
         n_ext += __shfl_down(n_ext, off);
         n_shadow += __shfl_down(n_shadow, off);
+        if (TRAV != 2) n_work64 += __shfl_down(n_work64, off);
     }
     if (lane == 0) {
         atomicAdd(&P.stats[0], n_paths);
         atomicAdd(&P.stats[1], n_ext);
         atomicAdd(&P.stats[2], n_shadow);
+        if (TRAV != 2) atomicAdd(&P.stats[3], n_work64);
     }
 #ifdef RT_INSTRUMENT
     for (int i = 0; i < RT_DBG_N; i++) {
         unsigned long long v = dbg.c[i];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0 && v) atomicAdd(&P.stats[3 + i], v);
+        if (lane == 0 && v) atomicAdd(&P.stats[4 + i], v);
     }
 #endif
 }

@@ -43,7 +43,7 @@ class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("ext_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("kernel_ms", C.c_double),
                 ("total_paths", C.c_uint64), ("total_ext_rays", C.c_uint64), ("total_shadow_rays", C.c_uint64),
                 ("total_kernel_ms", C.c_double), ("launches", C.c_uint32), ("_pad", C.c_uint32),
-                ("trace_kernel_ms", C.c_double), ("resolve_kernel_ms", C.c_double), ("reduce_ms", C.c_double)]
+                ("trace_kernel_ms", C.c_double), ("resolve_kernel_ms", C.c_double), ("reduce_ms", C.c_double), ("traversal_steps", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "_pad"}

@@ -3,8 +3,10 @@ bit-exactness spot check against the oracle on the first samples of a 1/8-scale 
 import os, sys, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import numpy as np, oracle, util
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import numpy as np, oracle, util, make_big_scene
 import rsoderh_raytracing_amd as R
+GRID = make_big_scene.make(4)
 env = R.Environment.synthetic(2048, 1024)
 oenv = util.oracle_env(env)
 rows = []
@@ -12,11 +14,12 @@ for label, scene, w, h, spp, mb in [
         ('config 2: default.toml 1280x720 64spp (as shipped, BVH)', 'default', 1280, 720, 64, 10),
         ('config 2b: spheres_only.toml 1280x720 64spp', 'spheres_only', 1280, 720, 64, 10),
         ('config 3: cube.toml 1280x720 128spp', 'cube', 1280, 720, 128, 10),
-        ('config 3b: suzanne.toml 1280x720 128spp (968 tris, 549 nodes; nodes + escape links in LDS)', 'suzanne', 1280, 720, 128, 10),
+        ('config 3b: suzanne.toml 1280x720 128spp (968 tris, 549 nodes; fixed-order walk, all nodes in LDS)', 'suzanne', 1280, 720, 128, 10),
+        ('config 3c: suzanne grid 4x4 1280x720 32spp (15,488 tris, 8,731 nodes; fixed-order walk, top 1,408 elements in LDS)', GRID, 1280, 720, 32, 10),
         ('config 4: house.toml 1920x1080 256spp 8 bounces', 'house', 1920, 1080, 256, 8),
         ('config 4b: house.toml 1920x1080 256spp 10 bounces (the reference constant)', 'house', 1920, 1080, 256, 10),
         ('interactive: house.toml 1920x1080, 1 spp per call (State::render)', 'house', 1920, 1080, 1, 10)]:
-    sc = R.Scene.load_toml(util.scene_path(scene))
+    sc = R.Scene.load_toml(scene if scene.endswith('.toml') else util.scene_path(scene))
     st = R.State.new(sc, env, w, h); st.max_bounces = mb
     for _ in range(1 if spp > 1 else 20):  # warm-up (clocks, allocations)
         st.render_range(0, spp)

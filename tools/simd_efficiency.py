@@ -1,5 +1,5 @@
 """Diagnostic: SIMD efficiency per code region of the wave-pool kernel, from the loop-trip counters of
-the instrumented build (RSRT_INSTRUMENT=1).  python tools/simd_efficiency.py [kernel_variant] [spp]"""
+the instrumented build (RSRT_INSTRUMENT=1).  python tools/simd_efficiency.py [kernel_variant] [spp] [scene name | path.toml] [w] [h] [bounces]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -10,12 +10,15 @@ import numpy as np
 import util
 import rsoderh_raytracing_amd as R
 env = R.Environment.synthetic(2048, 1024)
-sc = R.Scene.load_toml(util.scene_path(sys.argv[3] if len(sys.argv) > 3 else 'house'))
-st = R.State.new(sc, env, 1920, 1080); st.max_bounces = 8
+scene = sys.argv[3] if len(sys.argv) > 3 else 'house'
+sc = R.Scene.load_toml(scene if scene.endswith('.toml') else util.scene_path(scene))
+w, h, mb = (int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (1920, 1080, 8)
+st = R.State.new(sc, env, w, h); st.max_bounces = mb
 st.render_range(0, spp); st.synchronize()
 g = st.stats(); c = st.debug_counters().astype(np.float64)
 names = ['GEN', 'TRACE', 'MISS', 'SHADE', 'FINISH']
-print('kernel variant', os.environ['RSRT_KERNEL'], 'trace kernel %.1f ms' % g['trace_kernel_ms'], 'rays', g['ext_rays'] + g['shadow_rays'])
+print(os.path.basename(scene), ' '.join('%s=%s' % kv for kv in sorted(os.environ.items()) if kv[0].startswith('RSRT_')), 'trace kernel %.1f ms' % g['trace_kernel_ms'], 'rays', g['ext_rays'] + g['shadow_rays'],
+      'traversal steps/ray %.1f' % (g['traversal_steps'] / (g['ext_rays'] + g['shadow_rays'])))
 for i, n in enumerate(names):
     if c[i]:
         print('  stage %-5s invocations %12.0f  avg lanes %.1f / 64' % (n, c[i], c[5 + i] / c[i]))

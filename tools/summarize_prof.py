@@ -4,7 +4,6 @@ import glob
 import json
 import os
 import sys
-from collections import defaultdict
 
 out = sys.argv[1]
 
@@ -16,16 +15,22 @@ def rows(pattern):
                 yield r
 
 
-print("== bench line (under rocprofv3 --kernel-trace --stats) ==")
+def load(name):
+    with open(os.path.join(out, name)) as f:
+        lines = [l for l in f.read().splitlines() if l.startswith("{")]
+    return json.loads(lines[-1])
+
+
+print("== bench line under rocprofv3 --kernel-trace --stats (3 frames, no counters) ==")
 try:
-    b = json.load(open(os.path.join(out, "bench.json")))
+    b = load("bench_under_rocprof.json")
     print(json.dumps({k: b[k] for k in ("metric", "value", "unit", "ms_per_step", "kernel_ms_per_frame", "config")}))
 except Exception as e:  # noqa: BLE001
     print("no bench line:", e)
 
 print("\n== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for r in rows("trace/**/*kernel_stats.csv"):
-    print("%-60s calls %6s  total %14s ns  avg %14s ns  %6s %%" % (r.get("Name", "")[:60], r.get("Calls"), r.get("TotalDurationNs"),
+    print("%-64s calls %6s  total %14s ns  avg %16s ns  %8s %%" % (r.get("Name", "")[:64], r.get("Calls"), r.get("TotalDurationNs"),
                                                                    r.get("AverageNs"), r.get("Percentage")))
 print("\n== per-dispatch resources (kernel trace) ==")
 seen = set()
@@ -34,32 +39,23 @@ for r in rows("trace/**/*kernel_trace.csv"):
     if n in seen:
         continue
     seen.add(n)
-    print("%-60s grid %s wg %s  VGPR %s accumVGPR %s SGPR %s LDS %s scratch %s" % (
-        n[:60], r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"),
-        r.get("LDS_Block_Size"), r.get("Scratch_Size")))
+    print("%-64s wg %s  VGPR %s accumVGPR %s SGPR %s LDS %s scratch %s" % (
+        n[:64], r.get("Workgroup_Size"), r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size")))
 
-print("\n== PMC (separate runs, 1 frame each; sums over dispatches of each kernel) ==")
-acc = defaultdict(lambda: defaultdict(float))
-cnt = defaultdict(lambda: defaultdict(int))
-for r in rows("pmc*/**/*counter_collection.csv"):
-    k, c = r.get("Kernel_Name", ""), r.get("Counter_Name", "")
-    try:
-        acc[k][c] += float(r.get("Counter_Value", "0"))
-        cnt[k][c] += 1
-    except ValueError:
-        pass
-for k in acc:
-    if "rt_" not in k:
-        continue
-    print(k[:70])
-    for c in sorted(acc[k]):
-        print("    %-28s %18.0f  (%d dispatch rows)" % (c, acc[k][c], cnt[k][c]))
-    a = acc[k]
-    if "SQ_ACTIVE_INST_VALU" in a and "SQ_BUSY_CYCLES" in a and a["SQ_BUSY_CYCLES"]:
-        print("    derived: VALU active / wave cycles = %.3f ; lanes active per VALU inst = %.1f of 64" % (
-            a["SQ_ACTIVE_INST_VALU"] / max(a.get("SQ_WAVE_CYCLES", 1), 1),
-            a.get("SQ_THREAD_CYCLES_VALU", 0) / max(a["SQ_ACTIVE_INST_VALU"], 1)))
-    if "FETCH_SIZE" in a or "WRITE_SIZE" in a:
-        # guide: FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE under-reports wide coalesced streams by 2x on gfx950
-        print("    HBM-side traffic: FETCH_SIZE %.3f GB (x2 correction: %.3f GB), WRITE_SIZE %.3f GB" % (
-            a.get("FETCH_SIZE", 0) * 1024 / 1e9, a.get("FETCH_SIZE", 0) * 2048 / 1e9, a.get("WRITE_SIZE", 0) * 1024 / 1e9))
+print("\n== bench line on its own (5 frames), PMC counters collected by bench.py in separate rocprofv3 --pmc passes ==")
+try:
+    b = load("bench.json")
+    ro = b.pop("roofline")
+    cpu = b.pop("cpu_baseline", None)
+    print(json.dumps(b))
+    c = ro.pop("counters", None) or {}
+    print("\nroofline object (counters listed below):")
+    print(json.dumps(ro, indent=1))
+    print("\ncounters of %s, one frame per pass (source: %s; library build %s):" % (ro.get("kernel"), ro.get("counters_source"), ro.get("counters_build_id")))
+    for k in sorted(c):
+        print("    %-28s %20.0f" % (k, c[k]))
+    if cpu:
+        print("\ncpu_baseline:")
+        print(json.dumps(cpu, indent=1))
+except Exception as e:  # noqa: BLE001
+    print("no bench line:", e)
