@@ -399,7 +399,19 @@ def main():
                 state.set_partition(rank, world, partition.TILE_W, partition.TILE_H)
                 collective = "torch-nccl"
         if collective == "torch-nccl":
-            nccl_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", device_index))
+            # probe it: on a box where the ranks share one GPU (a rehearsal) NCCL refuses the communicator
+            ok = torch.tensor([1], dtype=torch.int32)
+            try:
+                nccl_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", device_index))
+                probe = torch.ones(4, device="cuda")
+                dist.reduce(probe, dst=0, group=nccl_group)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                ok[0] = 0
+                log("torch nccl reduce unavailable (%s): the accumulators are reduced through gloo on the host" % (str(e).splitlines()[0][:120],))
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0:
+                collective, nccl_group = "gloo", None
 
     def step():
         acc.zero_()
@@ -478,7 +490,9 @@ def main():
                            "launch_ms_under_pmc": pmc["launch_ms_under_pmc"], "counters": pmc["counters"], "resolve": pmc["resolve"],
                            "algorithmic_bytes_per_path": per_path, "algorithmic_counts_1spp": counts,
                            "passes": PMC_PASSES, "source": "bench.py --write-profile (rocprofv3 --kernel-trace --pmc, separate passes)"}, f, indent=1)
-        result = {"metric": "Mrays/s, house.toml 1920x1080 256spp 8-bounce", "value": value, "unit": "Mrays/s",
+        metric = "Mrays/s, house.toml 1920x1080 256spp 8-bounce" if std_cfg else \
+            "Mrays/s, %s %dx%d %dspp %d-bounce" % (os.path.basename(args.scene), W, H, spp, args.bounces)
+        result = {"metric": metric, "value": value, "unit": "Mrays/s",
                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                   "config": {"workload": "%s.toml %dx%d %d spp %d bounces, synthetic 2048x1024 HDRI env" % (os.path.basename(args.scene).replace(".toml", ""), W, H, spp, args.bounces),

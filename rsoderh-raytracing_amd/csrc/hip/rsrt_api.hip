@@ -683,10 +683,12 @@ rsrt_status collect_stats(rsrt_context *ctx)
 
 // Which traversal TRACE runs (rt_wavepool.h, TRAV): the flat loop where the scene qualifies, else the fixed-order walk,
 // else (leaves longer than 8 primitives) the generic tree walk; RSRT_TRAVERSAL / RSRT_FLAT cap the choice for A/B runs.
-int select_traversal(const rsrt_context *ctx, const DevScene &sc, uint32_t max_bounces)
+int select_traversal(const rsrt_context *ctx, const DevScene &sc, uint32_t max_bounces, uint32_t flags)
 {
     if (ctx->max_traversal >= 2 && ctx->allow_flat && sc.flat_ok && max_bounces <= RT_FLAT_MAX_BOUNCES) return 2;
-    if (ctx->max_traversal >= 3 && sc.typed_leaves) return 3;
+    // RSRT_FLAG_PRUNE wants the reference's near-child-first order: a close hit found early is what lets later boxes be
+    // skipped (the fixed-order walk prunes 4 % of suzanne's steps, the near-first walk 8 %)
+    if (ctx->max_traversal >= 3 && sc.typed_leaves && !(flags & RSRT_FLAG_PRUNE)) return 3;
     if (ctx->max_traversal >= 1 && sc.typed_leaves) return 1;
     return 0;
 }
@@ -1395,7 +1397,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.sample_buf = ctx->sample_buf;
 
     const int kv = ctx->kernel_variant;
-    const int trav = select_traversal(ctx, P.scene, max_bounces);
+    const int trav = select_traversal(ctx, P.scene, max_bounces, flags);
     int sv = P.scene.lds_float4s != 0 ? 1 : 0;
     if (sv == 0 && kv != 0 && ctx->allow_hybrid) { // mid-size scene: what the chosen traversal's box steps touch, in LDS (the first kernel has no hybrid form)
         const uint32_t head = trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4;
