@@ -328,6 +328,11 @@ def main():
     if args.pmc_child:
         return pmc_child(args)
 
+    # stdout is for the ONE JSON line: libraries that write to fd 1 (RCCL prints a version banner when a communicator
+    # comes up) are sent to stderr for the whole run, the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -507,8 +512,10 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
     if result is not None:
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

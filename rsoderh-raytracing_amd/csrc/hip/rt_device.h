@@ -447,6 +447,9 @@ RT_DEV float environment_pixel_solid_angle(float v, const DevEnv &e) // :739-749
 #ifndef RT_PNODE_GLOBAL_FIRST
 #define RT_PNODE_GLOBAL_FIRST 0
 #endif
+#ifndef RT_TRI_PAIR
+#define RT_TRI_PAIR 1 // fixed-order walk: two triangle records in flight per trip of the leaf loop
+#endif
 typedef float rt_f4v __attribute__((ext_vector_type(4)));
 typedef uint32_t rt_u4v __attribute__((ext_vector_type(4)));
 RT_DEV float4 env_texel(const DevEnv &e, size_t i)
@@ -1188,6 +1191,40 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
         }                                                                                                           \
         h.t = better ? (t) : h.t;                                                                                   \
         h.ref = better ? (rec) : h.ref;
+#if RT_TRI_PAIR
+        // Two triangles per trip: the walk is bound by the latency of these dependent gathers, not by instruction issue,
+        // so both records are requested together and tested one after the other (the order is free: ties go by rank).
+        while (tri_m != 0u) {
+            DBG_WAVE_TICK(12);
+            DBG_ADD(13, 1);
+            const uint32_t pa = take_lowest(tri_m);
+            const bool two = tri_m != 0u;
+            const uint32_t pb = two ? take_lowest(tri_m) : pa;
+            uint32_t base_a = qi[0], base_b = qi[0];
+#pragma unroll
+            for (int j = 1; j < RT_LEAFQ; j++) {
+                base_a = ((pa >> 3) == (uint32_t)j) ? qi[j] : base_a;
+                base_b = ((pb >> 3) == (uint32_t)j) ? qi[j] : base_b;
+            }
+            const uint32_t rec_a = base_a + (pa & 7u), rec_b = base_b + (pb & 7u);
+            const float4 a0 = S.prim(4u * rec_a), a1 = S.prim(4u * rec_a + 1u), a2 = S.prim(4u * rec_a + 2u);
+            const float4 b0 = S.prim(4u * rec_b), b1 = S.prim(4u * rec_b + 1u), b2 = S.prim(4u * rec_b + 2u);
+            float u, v;
+            bool stop = false;
+            {
+                const float t = triangle_t(o, d, v3(a0.x, a0.y, a0.z), v3(a1.x, a1.y, a1.z), v3(a2.x, a2.y, a2.z), u, v);
+                RT_PRE_ACCEPT(t, rec_a)
+                stop = better & anyhit;
+            }
+            if (two & !stop) {
+                DBG_ADD(13, 1);
+                const float t = triangle_t(o, d, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z), v3(b2.x, b2.y, b2.z), u, v);
+                RT_PRE_ACCEPT(t, rec_b)
+                stop = better & anyhit;
+            }
+            if (stop) { cur = RT_END; tri_m = pl_m = sp_m = 0u; }
+        }
+#else
         while (tri_m != 0u) {
             DBG_WAVE_TICK(12);
             DBG_ADD(13, 1);
@@ -1202,6 +1239,7 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
             RT_PRE_ACCEPT(t, rec)
             if (better & anyhit) { cur = RT_END; tri_m = pl_m = sp_m = 0u; }
         }
+#endif
         while (pl_m != 0u) {
             DBG_WAVE_TICK(15);
             DBG_ADD(13, 1);
