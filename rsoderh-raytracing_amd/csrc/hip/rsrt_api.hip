@@ -1241,6 +1241,7 @@ rsrt_status rsrt_environment_build_alias(rsrt_context *ctx, uint32_t slot, rsrt_
     hipLaunchKernelGGL(rt_alias_scan_kernel, dim3(1), dim3(1024), 0, q, blocks, nb, scalars + 1);
     hipLaunchKernelGGL(rt_alias_scatter_kernel, dim3(nb), dim3(256), 0, q, p, n, blocks, small, large);
     hipLaunchKernelGGL(rt_alias_vose_kernel, dim3(1), dim3(64), 0, q, p, n, small, scalars + 1, large, e.alias, scalars + 2);
+    hipLaunchKernelGGL(rt_alias_pmf_kernel, dim3(nb), dim3(256), 0, q, p, n, e.alias);
     HIP_TRY(ctx, hipGetLastError());
     uint32_t left = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&left, scalars + 2, 4, hipMemcpyDeviceToHost, q));

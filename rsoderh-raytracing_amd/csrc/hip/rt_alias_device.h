@@ -130,7 +130,9 @@ __global__ void rt_alias_scatter_kernel(const float *p, size_t n, const uint32_t
 // (wave-uniform: LDS broadcast reads), lane 0 stores the entries.  A large that stays >= 1 is pushed back and popped
 // again at once; a large that drops below 1 is pushed on `small` and is the very next small popped: both are carried
 // in registers, so memory is only touched for NEW stack entries — in stack order, from the back — and those are staged
-// RT_ALIAS_CHUNK at a time by all 64 lanes (coalesced index loads, parallel gathers of p).
+// RT_ALIAS_CHUNK at a time by all 64 lanes (coalesced index loads, parallel gathers of p) and read one entry AHEAD of
+// their use, so that the LDS latency overlaps the arithmetic of the current pair.  The loop stores {probability,
+// alias} only; pmf = p / N of the entries that were assigned is a data-parallel pass afterwards (rt_alias_pmf_kernel).
 __global__ __launch_bounds__(64) void rt_alias_vose_kernel(const float *p, size_t n, const uint32_t *small, const uint32_t *n_small_ptr,
                                                            const uint32_t *large, uint4 *out, uint32_t *leftover_out)
 {
@@ -138,51 +140,66 @@ __global__ __launch_bounds__(64) void rt_alias_vose_kernel(const float *p, size_
     __shared__ float s_p[RT_ALIAS_CHUNK], l_p[RT_ALIAS_CHUNK];
     const uint32_t lane = threadIdx.x;
     const uint32_t n_small = rt_uniform(*n_small_ptr), n_large = (uint32_t)n - n_small;
-    const float nf = (float)n;
-    uint32_t s_left = n_small, l_left = n_large; // entries of the original stacks not yet popped
+    uint32_t s_left = n_small, l_left = n_large; // entries of the original stacks not yet fetched
     uint32_t s_pos = 0, s_have = 0, l_pos = 0, l_have = 0; // staging windows
+    // the next entry of each original stack, fetched ahead
+    bool ns_ok = false, nl_ok = false;
+    uint32_t ns_i = 0, nl_i = 0;
+    float ns_p = 0.0f, nl_p = 0.0f;
+#define RT_ALIAS_FETCH(left, pos, have, idx, pv, stack, ok, oi, op)                                                         \
+    do {                                                                                                                    \
+        if ((left) == 0u) { ok = false; break; }                                                                            \
+        if ((pos) == (have)) { /* refill: the next (up to) CHUNK entries from the back of the stack */                      \
+            RT_ALIAS_WAVE_SYNC();                                                                                           \
+            have = (left) < RT_ALIAS_CHUNK ? (left) : RT_ALIAS_CHUNK;                                                       \
+            for (uint32_t j = lane; j < (have); j += 64u) { const uint32_t i = stack[(left) - 1u - j]; idx[j] = i; pv[j] = p[i]; } \
+            pos = 0;                                                                                                        \
+            RT_ALIAS_WAVE_SYNC();                                                                                           \
+        }                                                                                                                   \
+        oi = idx[pos]; op = pv[pos]; ok = true;                                                                             \
+        pos++; left--;                                                                                                      \
+    } while (0)
+    RT_ALIAS_FETCH(s_left, s_pos, s_have, s_idx, s_p, small, ns_ok, ns_i, ns_p);
+    RT_ALIAS_FETCH(l_left, l_pos, l_have, l_idx, l_p, large, nl_ok, nl_i, nl_p);
     bool have_dem = false, have_cur = false;
     uint32_t dem_i = 0, cur_i = 0;
-    float dem_res = 0.0f, dem_p = 0.0f, cur_res = 0.0f, cur_p = 0.0f;
+    float dem_res = 0.0f, cur_res = 0.0f;
     uint32_t assigned = 0;
+    uint2 *out2 = reinterpret_cast<uint2 *>(out);
     for (;;) {
         uint32_t s;
-        float res_s, p_s;
+        float res_s;
         if (have_dem) {
-            s = dem_i; res_s = dem_res; p_s = dem_p; have_dem = false;
+            s = dem_i; res_s = dem_res; have_dem = false;
         } else {
-            if (s_left == 0u) break; // small.is_empty()
-            if (s_pos == s_have) { // refill: the next (up to) CHUNK entries from the back of `small`
-                RT_ALIAS_WAVE_SYNC();
-                s_have = s_left < RT_ALIAS_CHUNK ? s_left : RT_ALIAS_CHUNK;
-                for (uint32_t j = lane; j < s_have; j += 64u) { const uint32_t i = small[s_left - 1u - j]; s_idx[j] = i; s_p[j] = p[i]; }
-                s_pos = 0;
-                RT_ALIAS_WAVE_SYNC();
-            }
-            s = rt_uniform(s_idx[s_pos]); p_s = rt_uniform(s_p[s_pos]); res_s = p_s;
-            s_pos++; s_left--;
+            if (!ns_ok) break; // small.is_empty()
+            s = rt_uniform(ns_i); res_s = rt_uniform(ns_p);
+            RT_ALIAS_FETCH(s_left, s_pos, s_have, s_idx, s_p, small, ns_ok, ns_i, ns_p);
         }
         uint32_t l;
-        float res_l, p_l;
+        float res_l;
         if (have_cur) {
-            l = cur_i; res_l = cur_res; p_l = cur_p;
+            l = cur_i; res_l = cur_res;
         } else {
-            if (l_left == 0u) break; // large.is_empty(): the small just popped keeps its default entry
-            if (l_pos == l_have) {
-                RT_ALIAS_WAVE_SYNC();
-                l_have = l_left < RT_ALIAS_CHUNK ? l_left : RT_ALIAS_CHUNK;
-                for (uint32_t j = lane; j < l_have; j += 64u) { const uint32_t i = large[l_left - 1u - j]; l_idx[j] = i; l_p[j] = p[i]; }
-                l_pos = 0;
-                RT_ALIAS_WAVE_SYNC();
-            }
-            l = rt_uniform(l_idx[l_pos]); p_l = rt_uniform(l_p[l_pos]); res_l = p_l;
-            l_pos++; l_left--;
+            if (!nl_ok) break; // large.is_empty(): the small just popped keeps its default entry
+            l = rt_uniform(nl_i); res_l = rt_uniform(nl_p);
+            RT_ALIAS_FETCH(l_left, l_pos, l_have, l_idx, l_p, large, nl_ok, nl_i, nl_p);
         }
-        if (lane == 0) out[s] = uint4{as_u(res_s), l, as_u(p_s / nf), 0u}; // {probability, alias_index, pmf, pad} (:143-150)
+        if (lane == 0) out2[2u * (size_t)s] = uint2{as_u(res_s), l}; // {probability, alias_index} (:143-150); pmf: rt_alias_pmf_kernel
         assigned++;
         res_l = rt_uniform(res_l - (1.0f - res_s)); // :152
-        if (res_l < 1.0f) { have_dem = true; have_cur = false; dem_i = l; dem_res = res_l; dem_p = p_l; }
-        else { have_cur = true; cur_i = l; cur_res = res_l; cur_p = p_l; }
+        if (res_l < 1.0f) { have_dem = true; have_cur = false; dem_i = l; dem_res = res_l; }
+        else { have_cur = true; cur_i = l; cur_res = res_l; }
     }
+#undef RT_ALIAS_FETCH
     if (lane == 0) *leftover_out = (uint32_t)n - assigned;
+}
+
+// pmf of the assigned entries = p / N (:146); an assigned entry's alias is never itself, a leftover's always is
+__global__ void rt_alias_pmf_kernel(const float *p, size_t n, uint4 *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float nf = (float)n;
+    if (out[i].y != (uint32_t)i) out[i].z = as_u(p[i] / nf);
 }
