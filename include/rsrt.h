@@ -167,6 +167,9 @@ void rsrt_multi_destroy(rsrt_multi *m);
 const char *rsrt_multi_last_error(const rsrt_multi *m);
 uint32_t rsrt_multi_size(const rsrt_multi *m);
 rsrt_context *rsrt_multi_context(rsrt_multi *m, uint32_t i);
+/* 1: the frame is reduced by RCCL; 0: by peer copies + adds on devices[0] — librccl could not be loaded, or the list names
+ * one device twice, which is accepted only with RSRT_MULTI_ALLOW_SAME_DEVICE=1 (a rehearsal of N devices on one GPU). */
+int rsrt_multi_uses_rccl(const rsrt_multi *m);
 rsrt_status rsrt_multi_upload_scene(rsrt_multi *m,
                                     const rsrt_material *materials, uint32_t n_materials,
                                     const rsrt_sphere *spheres, uint32_t n_spheres,

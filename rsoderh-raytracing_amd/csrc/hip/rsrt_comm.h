@@ -191,9 +191,19 @@ rsrt_status rsrt_comm_reduce(rsrt_context *ctx, uint32_t root, void *recv_device
 struct rsrt_multi {
     std::vector<rsrt_context *> ctx;
     float4 *frame = nullptr; // on device ctx[0]: the reduced W*H RGBA32F sum
+    float4 *stage = nullptr; // on device ctx[0]: landing buffer of the peer-copy reduce (no RCCL)
     uint32_t frame_w = 0, frame_h = 0;
     std::string error;
 };
+
+// frame += part (the reduce without RCCL; every pixel has one non-zero contributor, so the order does not matter)
+__global__ void rt_add_frame_kernel(float4 *frame, const float4 *part, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = frame[i], b = part[i];
+    frame[i] = float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+}
 
 namespace {
 
@@ -228,8 +238,10 @@ rsrt_status multi_ensure_frame(rsrt_multi *m)
     rsrt_context *c0 = m->ctx[0];
     if (m->frame && m->frame_w == c0->acc_w && m->frame_h == c0->acc_h) return RSRT_OK;
     DeviceGuard g(c0->device);
-    if (m->frame) { (void)hipDeviceSynchronize(); (void)hipFree(m->frame); m->frame = nullptr; }
+    if (m->frame) { (void)hipDeviceSynchronize(); (void)hipFree(m->frame); (void)hipFree(m->stage); m->frame = m->stage = nullptr; }
     if (hipMalloc(&m->frame, (size_t)c0->acc_w * c0->acc_h * sizeof(float4)) != hipSuccess) return mfail(m, RSRT_ERR_OUT_OF_MEMORY, "multi frame buffer", "hipMalloc failed");
+    if (m->ctx.size() > 1 && !c0->comm && hipMalloc(&m->stage, (size_t)c0->acc_w * c0->acc_h * sizeof(float4)) != hipSuccess)
+        return mfail(m, RSRT_ERR_OUT_OF_MEMORY, "multi stage buffer", "hipMalloc failed");
     m->frame_w = c0->acc_w;
     m->frame_h = c0->acc_h;
     return RSRT_OK;
@@ -240,6 +252,30 @@ rsrt_status multi_reduce(rsrt_multi *m)
 {
     rsrt_status st = multi_ensure_frame(m);
     if (st) return st;
+    if (m->ctx.size() > 1 && !m->ctx[0]->comm) { // no RCCL (not installed, or the list names one device twice): peer copies + adds on devices[0]
+        rsrt_context *c0 = m->ctx[0];
+        DeviceGuard g(c0->device);
+        const size_t n = (size_t)c0->acc_w * c0->acc_h, bytes = n * sizeof(float4);
+        hipStream_t q = c0->stream;
+        if ((st = begin_work(c0, q))) return mfail(m, st, "multi reduce", rsrt_last_error(c0));
+        hipError_t e = hipMemcpyAsync(m->frame, c0->accum, bytes, hipMemcpyDeviceToDevice, q);
+        for (size_t i = 1; i < m->ctx.size() && e == hipSuccess; i++) {
+            rsrt_context *ci = m->ctx[i];
+            if (ci->last_valid) e = hipStreamWaitEvent(q, ci->last_event, 0); // after device i's renders
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(m->stage, c0->device, ci->accum, ci->device, bytes, q);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(rt_add_frame_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, q, m->frame, m->stage, n);
+                e = hipGetLastError();
+            }
+        }
+        if (e != hipSuccess) { (void)end_work(c0, q); return mfail(m, RSRT_ERR_HIP, "multi reduce (peer copies)", hipGetErrorString(e)); }
+        if ((st = end_work(c0, q))) return mfail(m, st, "multi reduce", rsrt_last_error(c0));
+        for (size_t i = 1; i < m->ctx.size(); i++) { // device i must not overwrite its accumulator before it has been copied
+            DeviceGuard gi(m->ctx[i]->device);
+            if (hipStreamWaitEvent(m->ctx[i]->stream, c0->last_event, 0) != hipSuccess) return mfail(m, RSRT_ERR_HIP, "multi reduce", "hipStreamWaitEvent failed");
+        }
+        return RSRT_OK;
+    }
     const bool grouped = m->ctx[0]->comm != nullptr;
     if (grouped && rccl().GroupStart() != ncclSuccess) return mfail(m, RSRT_ERR_COMM, "multi reduce", "ncclGroupStart failed");
     rsrt_status first = RSRT_OK;
@@ -258,12 +294,13 @@ extern "C" {
 const char *rsrt_multi_last_error(const rsrt_multi *m) { return m ? m->error.c_str() : g_multi_error.c_str(); }
 uint32_t rsrt_multi_size(const rsrt_multi *m) { return m ? (uint32_t)m->ctx.size() : 0u; }
 rsrt_context *rsrt_multi_context(rsrt_multi *m, uint32_t i) { return (m && i < m->ctx.size()) ? m->ctx[i] : nullptr; }
+int rsrt_multi_uses_rccl(const rsrt_multi *m) { return (m && !m->ctx.empty() && m->ctx[0]->comm) ? 1 : 0; }
 
 void rsrt_multi_destroy(rsrt_multi *m)
 {
     if (!m) return;
     for (rsrt_context *c : m->ctx) (void)rsrt_synchronize(c);
-    if (m->frame && !m->ctx.empty()) { DeviceGuard g(m->ctx[0]->device); (void)hipFree(m->frame); }
+    if (m->frame && !m->ctx.empty()) { DeviceGuard g(m->ctx[0]->device); (void)hipFree(m->frame); (void)hipFree(m->stage); }
     for (rsrt_context *c : m->ctx) rsrt_context_destroy(c); // destroys its communicator too
     delete m;
 }
@@ -273,9 +310,13 @@ rsrt_status rsrt_multi_create(const int *devices, uint32_t n_devices, rsrt_multi
     if (!out) return mfail(nullptr, RSRT_ERR_INVALID_ARGUMENT, "rsrt_multi_create", "out is NULL");
     *out = nullptr;
     if (!devices || n_devices == 0 || n_devices > 64) return mfail(nullptr, RSRT_ERR_INVALID_ARGUMENT, "rsrt_multi_create", "device list empty (or longer than 64)");
+    // A device may appear twice only for rehearsals (RSRT_MULTI_ALLOW_SAME_DEVICE=1: N "devices" on one GPU; RCCL refuses
+    // two ranks on one device, so the frame is then reduced by peer copies + adds, as it is when librccl is missing).
+    bool duplicates = false;
     for (uint32_t i = 0; i < n_devices; i++)
-        for (uint32_t j = 0; j < i; j++)
-            if (devices[i] == devices[j]) return mfail(nullptr, RSRT_ERR_INVALID_ARGUMENT, "rsrt_multi_create", "a device appears twice in the list");
+        for (uint32_t j = 0; j < i; j++) duplicates = duplicates || devices[i] == devices[j];
+    const char *allow = getenv("RSRT_MULTI_ALLOW_SAME_DEVICE");
+    if (duplicates && !(allow && atoi(allow) != 0)) return mfail(nullptr, RSRT_ERR_INVALID_ARGUMENT, "rsrt_multi_create", "a device appears twice in the list");
     rsrt_multi *m = new rsrt_multi();
     for (uint32_t i = 0; i < n_devices; i++) {
         rsrt_context *c = nullptr;
@@ -287,8 +328,7 @@ rsrt_status rsrt_multi_create(const int *devices, uint32_t n_devices, rsrt_multi
         }
         m->ctx.push_back(c);
     }
-    if (n_devices > 1 && !rccl().ok) { mfail(nullptr, RSRT_ERR_COMM, "RCCL is not available", rccl().error.c_str()); rsrt_multi_destroy(m); return RSRT_ERR_COMM; }
-    if (rccl().ok) { // (a list of one device gets a communicator too: the same calls run whatever the list length)
+    if (rccl().ok && !duplicates) { // (a list of one device gets a communicator too: the same calls run whatever the list length)
         std::vector<ncclComm_t> comms(n_devices);
         const ncclResult_t r = rccl().CommInitAll(comms.data(), (int)n_devices, devices);
         if (r != ncclSuccess) { mfail(nullptr, RSRT_ERR_COMM, "ncclCommInitAll", rccl().GetErrorString(r)); rsrt_multi_destroy(m); return RSRT_ERR_COMM; }

@@ -27,7 +27,7 @@ _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "r
             "rsrt_partition_owner", "rsrt_partition_mask", "rsrt_comm_unique_id", "rsrt_comm_init", "rsrt_comm_reduce", "rsrt_comm_destroy",
             "rsrt_multi_create", "rsrt_multi_destroy", "rsrt_multi_last_error", "rsrt_multi_size", "rsrt_multi_context",
             "rsrt_multi_upload_scene", "rsrt_multi_upload_environment", "rsrt_multi_resize", "rsrt_multi_clear", "rsrt_multi_render",
-            "rsrt_multi_synchronize", "rsrt_multi_download", "rsrt_multi_display_srgb8", "rsrt_multi_get_stats"]
+            "rsrt_multi_synchronize", "rsrt_multi_download", "rsrt_multi_display_srgb8", "rsrt_multi_get_stats", "rsrt_multi_uses_rccl"]
 
 
 class RsrtError(RuntimeError):
@@ -111,6 +111,7 @@ def lib():
         L.rsrt_multi_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rsrt_multi_display_srgb8.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
         L.rsrt_multi_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.rsrt_multi_uses_rccl.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -345,6 +346,9 @@ class MultiState:
 
     def size(self):
         return self._L.rsrt_multi_size(self._m)
+
+    def uses_rccl(self):
+        return bool(self._L.rsrt_multi_uses_rccl(self._m))
 
     def clear(self):
         self._check(self._L.rsrt_multi_clear(self._m), "rsrt_multi_clear")

@@ -148,3 +148,33 @@ def test_device_list_state_equals_the_oracle(n):
     assert np.array_equal(util.bits(img), util.bits(ref5))
     assert np.array_equal(shown, host.display_srgb8(ref5, 5))
     assert (stats["paths"], stats["ext_rays"], stats["shadow_rays"]) == (ost["paths"], ost["ext_rays"], ost["shadow_rays"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_device_list_rehearsed_on_one_gpu(n, monkeypatch):
+    """N "devices" that are all GPU 0 (RSRT_MULTI_ALLOW_SAME_DEVICE=1): N contexts, N interleaved tile partitions, N
+    kernels, and the reduce that rsrt_multi falls back to when RCCL cannot be used (peer copies + adds on devices[0];
+    RCCL refuses two ranks on one device).  Everything of the N > 1 path except RCCL itself, on the hardware at hand."""
+    import oracle
+    from rsoderh_raytracing_amd import host
+    monkeypatch.setenv("RSRT_MULTI_ALLOW_SAME_DEVICE", "1")
+    sc = R.Scene.load_toml(util.scene_path("house"))
+    env = util.small_env()
+    w, h = 150, 70
+    ms = state.MultiState(sc, env, w, h, devices=[0] * n)
+    assert ms.size() == n and not ms.uses_rccl()
+    ms.max_bounces = 8
+    ms.render_samples(2)
+    first = ms.download()
+    ms.render_samples(3)
+    img, shown, stats = ms.download(), ms.display_srgb8(), ms.stats()
+    again = ms.download()  # a second reduce of the same accumulators gives the same frame
+    ms.close()
+    osc, oenv, cam = util.oracle_scene(sc), util.oracle_env(env), sc.camera_uniform().view(oracle.CAMERA)
+    ref2, _ = oracle.render(osc, oenv, cam, w, h, 0, 2, 8)
+    ref5, ost = oracle.render(osc, oenv, cam, w, h, 0, 5, 8)
+    assert np.array_equal(util.bits(first), util.bits(ref2))
+    assert np.array_equal(util.bits(img), util.bits(ref5)) and np.array_equal(util.bits(again), util.bits(ref5))
+    assert np.array_equal(shown, host.display_srgb8(ref5, 5))
+    assert (stats["paths"], stats["ext_rays"], stats["shadow_rays"]) == (ost["paths"], ost["ext_rays"], ost["shadow_rays"])
