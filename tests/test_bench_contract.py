@@ -1,0 +1,50 @@
+"""bench.py's roofline arithmetic on the committed counters (no GPU): the object must be a fraction of the roof the
+kernel is under, carry the counters and the build id it was taken on, and refuse nothing silently."""
+import json
+import os
+import sys
+
+import util
+
+sys.path.insert(0, util.ROOT)
+import bench  # noqa: E402
+
+
+def committed():
+    with open(os.path.join(util.ROOT, "profiles", "pmc_house_1080p_8b.json")) as f:
+        return json.load(f)
+
+
+def test_roofline_object_is_a_fraction_of_the_valu_roof():
+    c = committed()
+    pmc = {k: c[k] for k in ("counters", "resolve", "kernel", "build_id", "launch_ms_under_pmc")}
+    pmc["source"] = "committed"
+    paths = 1920 * 1080 * 256
+    ro = bench.roofline_object(pmc, c["build_id"], 114.0, paths, c["algorithmic_bytes_per_path"], 1920 * 1080, 256)
+    assert ro["bound"] == "valu" and ro["unit"].startswith("f32 lane-instructions")
+    assert 0.0 < ro["frac"] <= 1.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+    v = ro["valu"]
+    assert abs(ro["frac"] - v["issue_frac"] * 0.5 * v["lanes_active_per_instruction"] / 32.0) < 1e-9
+    assert 0.0 < v["wall"]["frac"] <= 1.0
+    assert "rt_render_pool_kernel" in ro["kernel"] and ro["counters_build_id"] == c["build_id"]
+    for k in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "WRITE_SIZE", "TCC_EA0_RDREQ_128B_sum"):
+        assert ro["counters"][k] > 0, k
+    h = ro["hbm"]
+    assert ro["traffic"] == h["fetch_bytes_per_launch"] + h["write_bytes_per_launch"] > 0
+    chk = h["resolve_kernel_check"]  # the resolve kernel streams a known byte count: the read counters agree within 1 %
+    assert abs(chk["counted_bytes"] / chk["known_bytes"] - 1.0) < 0.01
+    assert 0.0 < h["l2_hit_rate"] < 1.0 and 0.0 < ro["lds"]["array_busy_frac"] < 1.0
+    assert ro["algorithmic"]["frac_of_hbm_peak"] > 1.0  # ... which is exactly why HBM is not the roof that is reported
+
+
+def test_without_counters_the_object_says_so_and_carries_no_fraction():
+    ro = bench.roofline_object(None, "0123456789abcdef", 114.0, 1.0e6, 3450.0, 1000, 256)
+    assert ro["frac"] is None and ro["achieved"] is None and "no PMC counters" in ro["note"]
+    assert ro["algorithmic"]["bytes_per_path"] == 3450.0
+
+
+def test_committed_counters_belong_to_the_committed_kernel_sources():
+    """profiles/pmc_house_1080p_8b.json is bench.py's fallback when rocprofv3 cannot run; it is only attached when it was
+    taken on the library being timed, so it must be refreshed whenever a kernel source changes."""
+    from rsoderh_raytracing_amd import _build
+    assert committed()["build_id"] == _build.source_id(), "re-run tools/profile.sh r02_house on the GPU box and commit profiles/pmc_house_1080p_8b.json"
