@@ -1136,17 +1136,17 @@ template <class View>
 RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t quorum, uint32_t &cur,
                            Hit &h, const uint32_t *ref_mem, uint32_t &work)
 {
-    static_assert(RT_LEAFQ <= 4, "one byte of each 32-bit mask per held leaf");
+    static_assert(RT_LEAFQ >= 2 && RT_LEAFQ <= 4, "one byte of each 32-bit mask per held leaf; the leaf-loop vote rewinds to a second or later leaf");
     const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
     const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
     const uint32_t n_elems = sc.n_pnodes;
     uint32_t steps = 0;
     while (cur != RT_END && steps < budget) {
         DBG_WAVE_TICK(14);
-        uint32_t qi[RT_LEAFQ];
+        uint32_t qi[RT_LEAFQ], qe[RT_LEAFQ]; // held leaves: first record, and the walk element they were found at
         uint32_t nq = 0, all_m = 0, tri_m = 0, pl_m = 0;
 #pragma unroll
-        for (int j = 0; j < RT_LEAFQ; j++) qi[j] = 0u;
+        for (int j = 0; j < RT_LEAFQ; j++) qi[j] = qe[j] = 0u;
         // Lanes descend until they hold RT_LEAFQ leaves — but not for ever: rays need very different numbers of box steps
         // to get there (suzanne grid: 22 on average, 60 for the slowest lane of a wave), and every lane that is done
         // idles until the last one is.  So the wave takes a vote each trip and stops descending once fewer than
@@ -1167,7 +1167,10 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
             if (inside & leaf) {
                 const uint32_t idx = w0 & 0x7fffffffu, len = w1 & 0xffffu, hi = w1 >> 16; // triangle mask | plane mask << 8
 #pragma unroll
-                for (int j = 0; j < RT_LEAFQ; j++) qi[j] = (nq == (uint32_t)j) ? idx : qi[j];
+                for (int j = 0; j < RT_LEAFQ; j++) {
+                    qi[j] = (nq == (uint32_t)j) ? idx : qi[j];
+                    qe[j] = (nq == (uint32_t)j) ? cur : qe[j];
+                }
                 const uint32_t sh = 8u * nq;
                 all_m |= ((1u << len) - 1u) << sh;
                 tri_m |= (hi & 0xffu) << sh;
@@ -1194,6 +1197,12 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
 #if RT_TRI_PAIR
         // Two triangles per trip: the walk is bound by the latency of these dependent gathers, not by instruction issue,
         // so both records are requested together and tested one after the other (the order is free: ties go by rank).
+        // The same vote ends the triangle loop: lanes hold between none and twenty triangles, and the few with long
+        // lists would keep the whole wave (29 % of the lanes busy, measured).  A lane that is cut short needs no state
+        // saved: it REWINDS its cursor to the walk element of its first leaf with untested primitives and finds that
+        // leaf (and the ones after it) again when it is next scheduled; a triangle tested twice gives the same t and
+        // loses the tie against itself.
+        const uint32_t tri_started = (uint32_t)__popcll(__ballot(tri_m != 0u));
         while (tri_m != 0u) {
             DBG_WAVE_TICK(12);
             DBG_ADD(13, 1);
@@ -1223,6 +1232,20 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
                 stop = better & anyhit;
             }
             if (stop) { cur = RT_END; tri_m = pl_m = sp_m = 0u; }
+            // (wave-uniform.)  Never before every lane is through the triangles of its FIRST leaf: each round then completes
+            // at least one leaf per lane, so a ray that is cut short again and again still advances
+            if (__ballot((tri_m & 0xffu) != 0u) == 0ull && (uint32_t)__popcll(__ballot(tri_m != 0u)) * 100u < tri_started * quorum) break;
+        }
+        if (tri_m != 0u) { // cut short: back to the first leaf with untested triangles (>= 1); the planes / spheres of the leaves before it are still tested below
+            const uint32_t first = (uint32_t)__builtin_ctz(tri_m) >> 3;
+            uint32_t back = qe[1];
+#pragma unroll
+            for (int j = 2; j < RT_LEAFQ; j++) back = (first == (uint32_t)j) ? qe[j] : back;
+            cur = back;
+            const uint32_t keep = (1u << (8u * first)) - 1u;
+            tri_m = 0u;
+            pl_m &= keep;
+            sp_m &= keep;
         }
 #else
         while (tri_m != 0u) {
