@@ -1,0 +1,319 @@
+"""A SECOND, independent reading of the reference's shading and environment code (companion of
+test_independent_geometry.py): the BSDF (make_bsdf_material .. bsdf_sample, shader.wgsl:850-1202), the frames
+(:45-84), power_heuristic (:1206-1210), the equirectangular maps, the alias-method pick, sample_environment and
+environment_direction_pdf (:689-831) and the bilinear clamp-to-edge fetch (src/state.rs:134-142), restated in numpy
+float64 straight from the WGSL text, with its own PCG.  Compared with the oracle's functions on random inputs to 1e-4
+relative, except where a float64 and an f32 evaluation may legitimately take different branches (a comparison within
+1e-6 of its threshold)."""
+import ctypes as C
+
+import numpy as np
+
+import oracle
+import util
+import rsoderh_raytracing_amd as R
+
+PI = float(np.float32(3.14159))        # shader.wgsl:239 (not pi)
+INV_PI = float(np.float32(1.0 / 3.14159))
+M32 = 0xFFFFFFFF
+
+
+class Skip(Exception):
+    """a branch decision too close to its threshold for float64 and f32 to be expected to agree"""
+
+
+def guard(x, threshold, eps=1e-6):
+    if abs(x - threshold) < eps * max(1.0, abs(threshold)):
+        raise Skip()
+
+
+# ---- RNG (shader.wgsl:605-623)
+def rng_next(state):
+    state = (state * 747796405 + 2891336453) & M32
+    r = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & M32
+    return state, ((r >> 22) ^ r) & M32
+
+
+def uniform(state):
+    state, r = rng_next(state)
+    return state, float(np.float32(r)) / 4294967296.0  # f32(r) / 4294967295.0 with the divisor rounded to 2^32
+
+
+def normalize(v):
+    return v / np.sqrt(v @ v)
+
+
+def saturate(x):
+    return min(max(x, 0.0), 1.0)
+
+
+# ---- frames (:45-84)
+def make_frame(n):
+    helper = np.array([0.0, 0.0, 1.0]) if abs(n[2]) < 0.999 else np.array([1.0, 0.0, 0.0])  # select(f, t, cond)
+    guard(abs(n[2]), 0.999)
+    t = normalize(np.cross(helper, n))
+    return t, np.cross(n, t), n
+
+
+def to_local(f, w):
+    return np.array([w @ f[0], w @ f[1], w @ f[2]])
+
+
+def to_world(f, l):
+    return normalize(f[0] * l[0] + f[1] * l[1] + f[2] * l[2])
+
+
+# ---- BSDF (:850-1202)
+class Mat:
+    def __init__(self, color, roughness, metallic):
+        self.color = np.asarray(color, np.float64)
+        self.metallic = float(metallic)
+        self.alpha = max(0.001, float(roughness) * float(roughness))
+        t = saturate(self.metallic)
+        self.f0 = (1.0 - t) * np.array([0.04, 0.04, 0.04]) + t * self.color
+
+    def kd(self):
+        return self.color * (1 - saturate(self.metallic)) * (1 - max(self.f0))
+
+    def p_spec(self):
+        return saturate(0.2126 * self.f0[0] + 0.7152 * self.f0[1] + 0.0722 * self.f0[2])
+
+
+def d_ggx(ndh, a):
+    a2 = a * a
+    den = ndh * ndh * (a2 - 1.0) + 1.0
+    return a2 / (PI * den * den)
+
+
+def g1(ndv, a):
+    lam = (np.sqrt(1 + a * a * (1 - ndv * ndv) / (ndv * ndv)) - 1) / 2
+    return 1.0 / (1 + lam)
+
+
+def bsdf_eval(wo, wi, m):
+    if wo[2] <= 0 or wi[2] <= 0:
+        return np.zeros(3)
+    h = normalize(wo + wi)
+    D = d_ggx(saturate(h[2]), m.alpha)
+    G = g1(wo[2], m.alpha) * g1(wi[2], m.alpha)
+    x = 1 - saturate(h @ wo)
+    F = m.f0 + (1.0 - m.f0) * (x * x * x * x * x)
+    return m.kd() * (1 / PI) + (D * G) / (4 * wo[2] * wi[2]) * F
+
+
+def bsdf_pdf(wo, wi, m):
+    if wo[2] <= 0 or wi[2] <= 0:
+        return 0.0
+    ps = m.p_spec()
+    h = normalize(wo + wi)
+    wdh = abs(wo @ h)
+    if wdh <= 0:
+        spec = 0.0
+    else:
+        hv = 0.0 if h[2] <= 0 else d_ggx(h[2], m.alpha) * g1(wo[2], m.alpha) * max(0.0, wo @ h) / wo[2]
+        spec = hv / (4 * wdh)
+    return (1 - ps) * (wi[2] / PI) + ps * spec
+
+
+def bsdf_sample(ray_dir, n, m, state):
+    """-> (direction, scattering, pdf, state)"""
+    wo_w = -ray_dir
+    guard(n @ wo_w, 0.0)
+    if n @ wo_w <= 0:
+        return np.zeros(3), np.array([0.0, 0.0, 1.0]), 0.0, state
+    f = make_frame(n)
+    wo = to_local(f, wo_w)
+    if wo[2] <= 0:
+        return np.zeros(3), np.array([0.0, 1.0, 0.0]), 0.0, state
+    ps = m.p_spec()
+    pd = 1 - ps
+    state, s = uniform(state)
+    guard(s, pd)
+    if s < pd:
+        state, s1 = uniform(state)
+        r, phi = np.sqrt(s / max(pd, 1e-6)), 2 * PI * s1
+        x, y = r * np.cos(phi), r * np.sin(phi)
+        wi = np.array([x, y, np.sqrt(max(0.0, 1 - x * x - y * y))])
+    else:
+        state, s1 = uniform(state)
+        s0 = (s - pd) / max(ps, 1e-6)
+        vs = normalize(wo * np.array([m.alpha, m.alpha, 1.0]))
+        l2 = vs[0] * vs[0] + vs[1] * vs[1]
+        tx = np.array([-vs[1], vs[0], 0.0]) / np.sqrt(l2) if l2 > 0 else np.array([1.0, 0.0, 0.0])
+        ty = np.cross(vs, tx)
+        radius, az = np.sqrt(s0), 2 * PI * s1
+        dx, dy = radius * np.cos(az), radius * np.sin(az)
+        a = np.sqrt(max(0.0, 1 - dx * dx))
+        dy = (1 - vs[2]) * a + vs[2] * dy  # lerp_f32(a, dy, vs.z)
+        hs = dx * tx + dy * ty + np.sqrt(max(0.0, 1 - dx * dx - dy * dy)) * vs
+        h = normalize(np.array([m.alpha * hs[0], m.alpha * hs[1], max(0.0, hs[2])]))
+        i = -wo
+        wi = i - 2 * (h @ i) * h  # reflect(-wo, h)
+        guard(wi[2], 0.0, 1e-5)
+        if wi[2] <= 0:
+            return np.array([1.0, 0.0, 0.0]), np.array([1.0, 0.0, 0.0]), 0.0, state
+    sc, pdf = bsdf_eval(wo, wi, m), bsdf_pdf(wo, wi, m)
+    wi_w = to_world(f, wi)
+    if n @ wi_w < 0:
+        return np.zeros(3), np.array([0.0, 1.0, 0.0]), 0.0, state
+    return wi_w, sc, pdf, state
+
+
+# ---- environment (:689-831; sampler: linear magnification, clamp-to-edge, src/state.rs:134-142)
+def dir_to_uv(d):
+    return np.arctan2(d[2], d[0]) * INV_PI * 0.5 + 0.5, 0.5 - np.arcsin(d[1]) * INV_PI
+
+
+def uv_to_dir(u, v):
+    phi, theta = (2 * u - 1) * PI, PI * v
+    return np.array([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)])
+
+
+def solid_angle(v, w, h):
+    return (2 * PI / w) * (PI / h) * max(1e-6, np.sin(PI * v))
+
+
+def bilinear(rgba, u, v):
+    h, w = rgba.shape[:2]
+    x, y = u * w - 0.5, v * h - 0.5
+    x0, y0 = int(np.floor(x)), int(np.floor(y))
+    fx, fy = x - x0, y - y0
+    cx = lambda k: min(max(k, 0), w - 1)  # noqa: E731
+    cy = lambda k: min(max(k, 0), h - 1)  # noqa: E731
+    t = lambda xx, yy: rgba[cy(yy), cx(xx), :3].astype(np.float64)  # noqa: E731
+    top = t(x0, y0) * (1 - fx) + t(x0 + 1, y0) * fx
+    bot = t(x0, y0 + 1) * (1 - fx) + t(x0 + 1, y0 + 1) * fx
+    return top * (1 - fy) + bot * fy
+
+
+def trunc_u32(x, eps=1e-4):
+    if abs(x - round(x)) < eps:
+        raise Skip()
+    return 0 if x <= 0 else int(x)
+
+
+def env_pdf(env, d):
+    u, v = dir_to_uv(d)
+    x = min(trunc_u32(u * env.width), env.width - 1)
+    y = min(trunc_u32(v * env.height), env.height - 1)
+    return float(env.alias["pmf"][x + y * env.width]) / solid_angle(v, env.width, env.height)
+
+
+def sample_env(env, state):
+    n = env.width * env.height
+    state, u1 = uniform(state)
+    index = min(trunc_u32(u1 * n, 1e-3), n - 1)
+    e = env.alias[index]
+    state, u2 = uniform(state)
+    guard(u2, float(e["probability"]))
+    pick = index if u2 < float(e["probability"]) else int(e["alias_index"])  # the coin is ALWAYS drawn
+    x, y = pick % env.width, pick // env.width
+    state, jx = uniform(state)
+    state, jy = uniform(state)
+    u, v = (x + jx) / env.width, (y + jy) / env.height
+    return uv_to_dir(u, v), bilinear(env.rgba, u, v), float(env.alias["pmf"][pick]) / solid_angle(v, env.width, env.height), state
+
+
+# ---- the comparisons
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_bsdf_functions_agree_with_an_independent_float64_reading():
+    L = oracle.lib()
+    L.orc_bsdf_pdf_local.restype = C.c_float
+    L.orc_bsdf_sample.restype = C.c_float
+    rng = np.random.default_rng(3)
+    mats = np.concatenate([R.Scene.load_toml(util.scene_path(n)).materials.view(oracle.MATERIAL) for n in ("house", "default")])
+    checked = 0
+    for trial in range(1500):
+        m = mats[trial % len(mats):trial % len(mats) + 1]
+        mm = Mat(m["color"][0], m["roughness"][0], m["metallic"][0])
+        # eval + pdf on random upper-hemisphere (and some lower-hemisphere) directions
+        wo, wi = normalize(rng.normal(size=3)), normalize(rng.normal(size=3))
+        if trial % 5:
+            wo[2], wi[2] = abs(wo[2]), abs(wi[2])
+        wo32, wi32 = wo.astype(np.float32), wi.astype(np.float32)
+        out = np.zeros(3, np.float32)
+        L.orc_bsdf_eval_local(ptr(m), ptr(wo32), ptr(wi32), ptr(out))
+        pdf = L.orc_bsdf_pdf_local(ptr(m), ptr(wo32), ptr(wi32))
+        want_f, want_pdf = bsdf_eval(wo32.astype(np.float64), wi32.astype(np.float64), mm), bsdf_pdf(wo32.astype(np.float64), wi32.astype(np.float64), mm)
+        # a mirror-like lobe (roughness 0 -> alpha 0.001) evaluates 1 - ndh^2 + alpha^2 by cancellation: f32 and float64 then
+        # differ by per cent, legitimately; the comparison is sharp for the rougher materials
+        rtol = 2e-4 if mm.alpha >= 0.05 else 0.3
+        if min(wo32[2], wi32[2]) > 1e-3 or max(wo32[2], wi32[2]) <= 0:
+            assert np.allclose(out, want_f, rtol=rtol, atol=1e-6), (trial, out, want_f)
+            assert abs(pdf - want_pdf) <= rtol * max(1.0, abs(want_pdf)), (trial, pdf, want_pdf)
+        # sampling: same draws, same lobe, same direction
+        n = normalize(rng.normal(size=3)).astype(np.float32)
+        d = normalize(rng.normal(size=3)).astype(np.float32)
+        seed = int(rng.integers(0, 2 ** 32))
+        st = C.c_uint32(seed)
+        dir_out, sc_out = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        got_pdf = L.orc_bsdf_sample(ptr(m), ptr(d), ptr(n), C.byref(st), ptr(dir_out), ptr(sc_out))
+        try:
+            w_dir, w_sc, w_pdf, w_state = bsdf_sample(d.astype(np.float64), n.astype(np.float64), mm, seed)
+        except Skip:
+            continue
+        assert st.value == w_state, (trial, "the number of draws differs")
+        if w_pdf > 0 and w_dir[2] == w_dir[2] and abs(n.astype(np.float64) @ w_dir) < 1e-4:
+            continue  # grazing: the final sign test may go either way
+        assert np.allclose(dir_out, w_dir, atol=5e-4), (trial, dir_out, w_dir)
+        if mm.alpha >= 0.05:  # (a mirror-like lobe sampled at its peak: values of 1e8 that f32 cancellation moves by tens of per cent)
+            assert np.allclose(sc_out, w_sc, rtol=5e-3, atol=1e-5), (trial, sc_out, w_sc)
+            assert abs(got_pdf - w_pdf) <= 5e-3 * max(1.0, abs(w_pdf)), (trial, got_pdf, w_pdf)
+        else:
+            assert (got_pdf > 0) == (w_pdf > 0) and np.all((sc_out > 0) == (w_sc > 0)), (trial, got_pdf, w_pdf)
+        checked += 1
+    assert checked > 1000
+
+
+def test_environment_functions_agree_with_an_independent_float64_reading():
+    L = oracle.lib()
+    L.orc_environment_direction_pdf.restype = C.c_float
+    L.orc_sample_environment.restype = C.c_float
+    env = R.Environment.synthetic(64, 32)
+    oenv = util.oracle_env(env)
+    rng = np.random.default_rng(4)
+    checked = 0
+    for trial in range(1500):
+        d = normalize(rng.normal(size=3)).astype(np.float32)
+        uv = np.zeros(2, np.float32)
+        L.orc_direction_to_uv(ptr(d), ptr(uv))
+        assert np.allclose(uv, dir_to_uv(d.astype(np.float64)), atol=2e-5)
+        sky = np.zeros(3, np.float32)
+        L.orc_sky_light(C.byref(oenv.c), ptr(d), ptr(sky))
+        u, v = dir_to_uv(d.astype(np.float64))
+        assert np.allclose(sky, bilinear(env.rgba, u, v), rtol=2e-3, atol=1e-3), (trial, sky, bilinear(env.rgba, u, v))
+        try:
+            want = env_pdf(env, d.astype(np.float64))
+            got = L.orc_environment_direction_pdf(C.byref(oenv.c), ptr(d))
+            assert abs(got - want) <= 1e-3 * max(1.0, abs(want)), (trial, got, want)
+        except Skip:
+            pass
+        seed = int(rng.integers(0, 2 ** 32))
+        st = C.c_uint32(seed)
+        dir_out, rad = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        got_pdf = L.orc_sample_environment(C.byref(oenv.c), C.byref(st), ptr(dir_out), ptr(rad))
+        try:
+            w_dir, w_rad, w_pdf, w_state = sample_env(env, seed)
+        except Skip:
+            continue
+        assert st.value == w_state, (trial, "four draws per environment sample")
+        assert np.allclose(dir_out, w_dir, atol=1e-4), (trial, dir_out, w_dir)
+        assert np.allclose(rad, w_rad, rtol=2e-3, atol=1e-3), (trial, rad, w_rad)
+        assert abs(got_pdf - w_pdf) <= 1e-3 * max(1.0, abs(w_pdf)), (trial, got_pdf, w_pdf)
+        checked += 1
+    assert checked > 1300
+
+
+def test_power_heuristic_and_rng_uniform():
+    # shader.wgsl:1206-1210; :621-623
+    assert uniform(0x4712a88e)[1] == 0.234235808253288269043  # SURVEY KAT: first uniform of (pixel 0, sample 0), exactly representable
+    st = oracle.rng_seed(0, 0)
+    assert st == 0x4712a88e
+    draws, _ = oracle.rng_draws(st, 4)
+    s = st
+    for want in draws:
+        s, r = rng_next(s)
+        assert r == want
