@@ -16,6 +16,18 @@
 
 #include "../../../include/rsrt_detmath.h"
 
+// -DRT_FAST_NUMERICS (experiment build only; tools/fast_numerics.py): what the bit-exact numeric contract costs in run
+// time.  The hardware's own approximations replace the contract's functions — v_sin_f32 / v_cos_f32, ocml atan2f /
+// asinf, and (by the flags the tool adds: -fno-hip-fp32-correctly-rounded-divide-sqrt -ffp-contract=fast) the 2.5-ulp
+// division and square root and free fma contraction — everything WGSL would allow.  NOT a product mode: its image
+// cannot be validated against the 1e-3 bar ("What parity unpinned costs").
+#ifdef RT_FAST_NUMERICS
+#define rsrt_sinf __sinf
+#define rsrt_cosf __cosf
+#define rsrt_atan2f atan2f
+#define rsrt_asinf asinf
+#endif
+
 #define RT_DEV __device__ __forceinline__
 
 struct V3 {
@@ -63,6 +75,9 @@ RT_DEV uint32_t as_u(float f) { return __float_as_uint(f); }
 // compiler's full division; the empty asm keeps that path a branch instead of a select of both.
 RT_DEV float rt_rcp(float x)
 {
+#ifdef RT_FAST_NUMERICS
+    return __builtin_amdgcn_rcpf(x);
+#endif
     const uint32_t ex = (as_u(x) >> 23) & 0xffu;
     if (ex - 2u < 251u) {
         const float r0 = __builtin_amdgcn_rcpf(x);
