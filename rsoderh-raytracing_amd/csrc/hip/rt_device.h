@@ -1092,7 +1092,7 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
     }
     while (pl_m != 0ull) {
         DBG_WAVE_TICK(15);
-        DBG_ADD(13, 1);
+        DBG_ADD(13, 1); DBG_ADD(29, 1);
         const uint32_t rec = (uint32_t)__builtin_ctzll(pl_m);
         pl_m &= pl_m - 1ull;
         const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u), r3 = S.prim(4u * rec + 3u);
@@ -1102,7 +1102,7 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
     }
     while (sp_m != 0ull) {
         DBG_WAVE_TICK(28);
-        DBG_ADD(13, 1);
+        DBG_ADD(13, 1); DBG_ADD(30, 1);
         const uint32_t rec = (uint32_t)__builtin_ctzll(sp_m);
         sp_m &= sp_m - 1ull;
         const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u);

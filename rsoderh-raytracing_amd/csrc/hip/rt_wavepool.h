@@ -344,6 +344,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     const uint32_t hr = COLD(C_REF, slot);
                     h.ref = hr & 0x3fffffffu; h.src = hr >> 30;
                 }
+                DBG_ADD(27, (as_u(hit_record(S, h, 0).w) & 3u) == PRIM_TRIANGLE ? 1 : 0); DBG_ADD(31, (as_u(hit_record(S, h, 0).w) & 3u) == PRIM_SPHERE ? 1 : 0);
                 hit_barycentrics(S, h, o, d); // not carried through the traversal: the same test gives the same bits
                 uint32_t rng = COLD(C_RNG, slot);
                 V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 const V3 wo = to_frame_local(frame, -d);
                 V3 nee = v3(0.0f, 0.0f, 0.0f);
                 if (want_shadow) { // what :1247-1249 adds if the shadow ray comes back unoccluded
+                    DBG_WAVE_TICK(23); DBG_ADD(24, 1);
                     const V3 wi = to_frame_local(frame, es.direction);
                     V3 scattering;
                     float pdf_bsdf;

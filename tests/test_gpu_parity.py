@@ -254,21 +254,24 @@ def test_renders_on_different_caller_streams_are_one_chain(big_env):
     """rsrt_accumulator_clear runs on the context's own stream; renders may be put on any caller stream.  The work
     buffers and the accumulator belong to the context, so the library orders every enqueue after the previous one,
     whatever the stream: clear -> render on s1 -> render on s2 -> render on the context's stream == one render."""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # two caller streams straight from the HIP runtime the library itself uses
+    s1, s2 = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(s1)) == 0 and hip.hipStreamCreate(ctypes.byref(s2)) == 0
     sc = R.Scene.load_toml(util.scene_path("house"))
     w, h = 320, 180  # big enough that a render is still running when the next one is enqueued
     ref, _ = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), w, h, 0, 7, 8)
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     st = R.State.new(sc, big_env, w, h)
     st.max_bounces = 8
     for _ in range(3):  # the second and third round clear an accumulator that is full of samples
         st._last_hash = None
-        st.render_samples(3, stream=s1.cuda_stream)   # hash changed: clear (context stream), then samples 0..2 on s1
-        st.render_samples(2, stream=s2.cuda_stream)   # samples 3..4 on another stream, same sample buffer / path arena
+        st.render_samples(3, stream=s1.value)   # hash changed: clear (context stream), then samples 0..2 on s1
+        st.render_samples(2, stream=s2.value)   # samples 3..4 on another stream, same sample buffer / path arena
         st.render_samples(2)                          # samples 5..6 on the context's own stream
         img = st.download()
         assert np.array_equal(util.bits(img), util.bits(ref))
     st.close()
+    assert hip.hipStreamDestroy(s1) == 0 and hip.hipStreamDestroy(s2) == 0
 
 
 def test_sample_buffer_passes_do_not_change_the_image(big_env, monkeypatch):

@@ -35,3 +35,10 @@ if tot:
 if c[15] or c[28]:
     inv = max(c[1], 1)
     print('  typed leaf loops per TRACE invocation: triangle trips %.2f, plane trips %.2f, sphere trips %.2f' % (c[12] / inv, c[15] / inv, c[28] / inv))
+if c[29] or c[30]:
+    tri_l = c[13] - c[29] - c[30]
+    print('  flat primitive loops, lanes busy: triangles %.1f%% of %.3e wave trips, planes %.1f%% of %.3e, spheres %.1f%% of %.3e' % (
+        100 * tri_l / max(64 * c[12], 1), c[12], 100 * c[29] / max(64 * c[15], 1), c[15], 100 * c[30] / max(64 * c[28], 1), c[28]))
+if c[23]:
+    print('  SHADE: NEE evaluation branch taken in %.1f%% of the invocations at %.1f%% of the stage\'s lanes; hits on triangles %.1f%%, spheres %.1f%%' % (
+        100 * c[23] / max(c[3], 1), 100 * c[24] / max(c[8], 1), 100 * c[27] / max(c[8], 1), 100 * c[31] / max(c[8], 1)))
