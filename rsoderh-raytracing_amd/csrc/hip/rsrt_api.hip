@@ -306,7 +306,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_resolve_kernel(RenderParams P, fl
 // runs); TRAV == 4 is the first kernel's stack walk.  mode bit 0: cast_ray_bvh only (no brute-force fallback).
 template <int SV, int TRAV>
 __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uint32_t n, const float *origins, const float *dirs,
-                                                                uint32_t mode, uint32_t flags, rsrt_hit *out)
+                                                                uint32_t mode, uint32_t flags, uint32_t repeat, rsrt_hit *out)
 {
     if (SV != 0) stage_scene_lds(sc);
     const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
@@ -326,6 +326,16 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
 #endif
         uint32_t cur = 0, work = 0;
         while (cur != RT_END) trace_dispatch<(TRAV == 4 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, 50u, cur, h, nullptr, work);
+        // RSRT_PROBE_REPEAT (tools/trace_rate.py): the same query again and again, so that a timing of this kernel is a timing
+        // of the traversal and not of staging the scene for 256 rays; the result does not change
+        for (uint32_t k = 1; k < repeat; k++) {
+            asm volatile("" : "+v"(o.x), "+v"(d.x));
+            Hit h2;
+            h2.t = RT_INFINITY; h2.ref = 0; h2.src = SRC_BVH; h2.u = h2.v = 0.0f;
+            cur = 0;
+            while (cur != RT_END) trace_dispatch<(TRAV == 4 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, 50u, cur, h2, nullptr, work);
+            h.t = h2.t; h.ref = h2.ref; h.src = h2.src;
+        }
         if (h.did_hit()) hit_barycentrics(S, h, o, d); // as SHADE does: the traversals do not carry u, v
     }
     if ((mode & 1u) == 0 && !h.did_hit()) { // cast_ray's brute-force fallback (the MISS stage)
@@ -1560,7 +1570,9 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
     if (e == hipSuccess) {
         const size_t smem = (size_t)sc.lds_float4s * sizeof(float4) + (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t);
         if (smem > 160 * 1024) { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: needs %zu bytes of LDS", smem); }
-        void *kargs[] = {&sc, &n, &d_o, &d_d, &mode, &flags, &d_h};
+        uint32_t repeat = 1;
+        if (const char *pr = getenv("RSRT_PROBE_REPEAT")) { int v = atoi(pr); if (v > 1 && v <= 4096) repeat = (uint32_t)v; }
+        void *kargs[] = {&sc, &n, &d_o, &d_d, &mode, &flags, &repeat, &d_h};
         e = hipLaunchKernel(probe_function(sv, trav), dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), kargs, smem, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
