@@ -45,12 +45,17 @@ enum CtBits : uint32_t {
     CT_FLAGS = 120u,
     CT_SHIFT = 7u
 };
+#ifndef RT_RNG_HOT
+#define RT_RNG_HOT 1 // flat traversal: the RNG word travels in the H_T cell instead of a cold column (see the kernel)
+#endif
 enum ColdField {
-    C_TX, C_TY, C_TZ, C_LX, C_LY, C_LZ, C_NEEX, C_NEEY, C_NEEZ, C_LASTPDF, C_RNG, C_OUT,
-    C_COUNT_FLAT, // the flat traversal stops here: its bounce count and hit record ride in the idle cursor bits of H_CT
-    C_BOUNCE = C_COUNT_FLAT,
+    C_TX, C_TY, C_TZ, C_LX, C_LY, C_LZ, C_NEEX, C_NEEY, C_NEEZ, C_LASTPDF, C_OUT,
+    C_RNG, // (the flat traversal keeps it in a hot cell when RT_RNG_HOT)
+    C_BOUNCE,
     C_REF, // tree-walk traversals only: best hit of the extension ray, record | source << 30
-    C_COUNT
+    C_COUNT,
+    // the flat traversal stops early: its bounce count and hit record ride in the idle cursor bits of H_CT
+    C_COUNT_FLAT = RT_RNG_HOT ? C_RNG : C_BOUNCE
 };
 // RT_COLD_COMPACT=0 restores 14 cold columns for every traversal (A/B of the arena's L2 footprint)
 #ifndef RT_COLD_COMPACT
@@ -126,6 +131,12 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
 {
     typedef PoolLayout<POOL, TRAV> L;
     constexpr bool kBounceInCt = pool_cold_columns(TRAV) == (uint32_t)C_COUNT_FLAT; // no C_BOUNCE / C_REF column
+    // Flat traversal: every ray finishes in one TRACE call, so "best t so far" is INFINITY at every start and the H_T cell is
+    // only needed for the RESULT of the extension ray — which fits the shadow direction's first cell, dead by then (the
+    // shadow ray is traced first).  H_T then carries the RNG word instead of a cold column: SHADE's first dependent memory
+    // access, the alias-table gather, can leave with the cold loads instead of a memory round trip after them.
+    constexpr bool kRngHot = RT_RNG_HOT && TRAV == 2;
+    constexpr uint32_t kTCell = kRngHot ? (uint32_t)H_SX : (uint32_t)H_T; // where the extension ray's t waits for SHADE / MISS
     const DevScene &sc = P.scene;
     if (SV != 0) stage_scene_lds(sc);
     const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
@@ -231,11 +242,11 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                         start_path(P, px, py, P.sample_begin + srel, ps);
                         SETH(H_OX, slot, ps.o.x); SETH(H_OY, slot, ps.o.y); SETH(H_OZ, slot, ps.o.z);
                         SETH(H_EX, slot, ps.d.x); SETH(H_EY, slot, ps.d.y); SETH(H_EZ, slot, ps.d.z);
-                        SETH(H_T, slot, RT_INFINITY);
+                        if (kRngHot) HOT(H_T, slot) = ps.rng; else SETH(H_T, slot, RT_INFINITY);
                         SETC(C_TX, slot, 1.0f); SETC(C_TY, slot, 1.0f); SETC(C_TZ, slot, 1.0f);
                         SETC(C_LX, slot, 0.0f); SETC(C_LY, slot, 0.0f); SETC(C_LZ, slot, 0.0f);
                         SETC(C_LASTPDF, slot, 1.0f);
-                        COLD(C_RNG, slot) = ps.rng;
+                        if (!kRngHot) COLD(C_RNG, slot) = ps.rng;
                         if (!kBounceInCt) COLD(C_BOUNCE, slot) = 0u;
                         COLD(C_OUT, slot) = srel * P.n_slots + chunk_tile_slot0 + p;
                         SET_CT(slot, 0u, F_EXT, TAG_TRACE);
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 Hit h;
                 uint32_t cur = kBounceInCt ? 0u : (ct >> CT_SHIFT); // (flat: every ray finishes in one call, the bits carry the bounce count)
                 h.src = SRC_BVH;
-                h.t = HOTF(H_T, slot); h.u = h.v = 0.0f;
+                h.t = kRngHot ? RT_INFINITY : HOTF(H_T, slot); h.u = h.v = 0.0f;
                 // the record of an earlier call's best hit stays in the cold column unless beaten; the fixed-order walk, where
                 // an equal t can still replace it, fetches it from there if (and only if) such a tie comes up
                 h.ref = (TRAV == 3 && !shadow) ? RT_REF_UNKNOWN : 0u;
@@ -272,18 +283,18 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, P.descend_quorum, cur, h, &COLD(C_REF, slot), n_work);
                 const bool found = TRAV == 3 ? (h.ref != RT_REF_UNKNOWN) : (h.t < t_in); // this call found a closer (or earlier-ranked) hit
                 const bool done = cur == RT_END;
-                if (!done) { // to be resumed: best t and cursor
-                    SETH(H_T, slot, h.t);
+                if (!done) { // to be resumed: best t and cursor (never the flat traversal)
+                    if (!kRngHot) SETH(H_T, slot, h.t);
                     if (TRAV != 2 && !shadow && found) COLD(C_REF, slot) = h.ref;
                     SET_CT(slot, cur, ct & CT_FLAGS, TAG_TRACE);
                 } else if (shadow) {
                     n_shadow++;
-                    SETH(H_T, slot, RT_INFINITY); // the extension ray starts fresh
+                    if (!kRngHot) SETH(H_T, slot, RT_INFINITY); // the extension ray starts fresh
                     const uint32_t fl = (ct & (F_EXT | F_NEE)) | (h.t < RT_INFINITY ? (uint32_t)F_OCCLUDED : 0u);
                     SET_CT(slot, kBounceInCt ? (ct >> CT_SHIFT) : 0u, fl, (ct & F_EXT) ? TAG_TRACE : TAG_FINISH); // (keeps the bounce bits)
                 } else {
                     n_ext++;
-                    SETH(H_T, slot, h.t);
+                    SETH(kTCell, slot, h.t);
                     if (TRAV != 2 && found) COLD(C_REF, slot) = h.ref;
                     // the flat traversal's records fit the idle cursor bits: no cold column
                     SET_CT(slot, (TRAV == 2 ? h.ref : 0u) | (kBounceInCt ? (ct >> CT_SHIFT) : 0u), ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     if (t >= 0.0f && t < h.t) { h.t = t; h.ref = i; h.src = SRC_FB_PLANE; }
                 }
                 if (h.did_hit()) { // SHADE takes it from here (and settles the pending NEE term)
-                    SETH(H_T, slot, h.t);
+                    SETH(kTCell, slot, h.t);
                     if (TRAV == 2) {
                         SET_CT(slot, h.ref | (h.src << 6) | (kBounceInCt ? (ct >> CT_SHIFT) : 0u), ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
                     } else {
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
                 const V3 d = v3(HOTF(H_EX, slot), HOTF(H_EY, slot), HOTF(H_EZ, slot));
                 Hit h;
-                h.t = HOTF(H_T, slot);
+                h.t = HOTF(kTCell, slot);
                 if (TRAV == 2) {
                     const uint32_t hr = (ct >> CT_SHIFT) & 0xffu;
                     h.ref = hr & 63u; h.src = hr >> 6;
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 }
                 DBG_ADD(27, (as_u(hit_record(S, h, 0).w) & 3u) == PRIM_TRIANGLE ? 1 : 0); DBG_ADD(31, (as_u(hit_record(S, h, 0).w) & 3u) == PRIM_SPHERE ? 1 : 0);
                 hit_barycentrics(S, h, o, d); // not carried through the traversal: the same test gives the same bits
-                uint32_t rng = COLD(C_RNG, slot);
+                uint32_t rng = kRngHot ? HOT(H_T, slot) : COLD(C_RNG, slot);
                 V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
                 V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
                 const uint32_t bounce = (kBounceInCt ? (ct >> (CT_SHIFT + RT_FLAT_BOUNCE_SHIFT)) : COLD(C_BOUNCE, slot)) + 1u;
@@ -393,13 +404,13 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     if (!finished) {
                         SETC(C_LASTPDF, slot, bs.pdf);
                         SETC(C_TX, slot, T.x); SETC(C_TY, slot, T.y); SETC(C_TZ, slot, T.z);
-                        COLD(C_RNG, slot) = rng;
+                        if (kRngHot) HOT(H_T, slot) = rng; else COLD(C_RNG, slot) = rng;
                         if (!kBounceInCt) COLD(C_BOUNCE, slot) = bounce;
                         SETH(H_EX, slot, bs.dir.x); SETH(H_EY, slot, bs.dir.y); SETH(H_EZ, slot, bs.dir.z);
                     }
                     if (want_shadow) { SETH(H_SX, slot, es.direction.x); SETH(H_SY, slot, es.direction.y); SETH(H_SZ, slot, es.direction.z); }
                     SETH(H_OX, slot, surf.point.x); SETH(H_OY, slot, surf.point.y); SETH(H_OZ, slot, surf.point.z); // both rays start at the hit point
-                    SETH(H_T, slot, RT_INFINITY);
+                    if (!kRngHot) SETH(H_T, slot, RT_INFINITY);
                     SET_CT(slot, kBounceInCt ? (bounce << RT_FLAT_BOUNCE_SHIFT) : 0u,
                            (want_shadow ? (uint32_t)F_SHADOW : 0u) | (finished ? 0u : (uint32_t)F_EXT) | (nee_counts ? (uint32_t)F_NEE : 0u), TAG_TRACE);
                 }
