@@ -513,11 +513,24 @@ struct EnvironmentSample {
     V3 direction, radiance;
     float pdf;
 };
-RT_DEV EnvironmentSample sample_environment(const DevEnv &e, uint32_t &rng) // :782-820 + :689-706
+// sample_environment (:782-820 + :689-706) in two halves, so that a caller can put work between the alias-table gather —
+// a random 16-byte read of a 32 MB table, the first of two dependent memory round trips — and its use.
+struct EnvironmentPick {
+    uint32_t index;
+    uint4 entry;
+};
+RT_DEV EnvironmentPick sample_environment_begin(const DevEnv &e, uint32_t &rng) // first draw, gather issued
 {
-    uint32_t length = e.width * e.height;
-    uint32_t index = min(f2u(random_uniform(rng) * (float)length), length - 1u);
-    uint4 entry = env_alias_stream(e, index);
+    const uint32_t length = e.width * e.height;
+    EnvironmentPick p;
+    p.index = min(f2u(random_uniform(rng) * (float)length), length - 1u);
+    p.entry = env_alias_stream(e, p.index);
+    return p;
+}
+RT_DEV EnvironmentSample sample_environment_finish(const DevEnv &e, uint32_t &rng, const EnvironmentPick &p) // draws two to four
+{
+    const uint32_t index = p.index;
+    const uint4 entry = p.entry;
     float u2 = random_uniform(rng);
     uint32_t pick = (u2 < as_f(entry.x)) ? index : entry.y;
     uint32_t x, y; // pick % width, pick / width
@@ -532,6 +545,11 @@ RT_DEV EnvironmentSample sample_environment(const DevEnv &e, uint32_t &rng) // :
     float pmf = (pick == index) ? as_f(entry.z) : as_f(env_alias(e, pick).z);
     s.pdf = pmf / environment_pixel_solid_angle(v, e);
     return s;
+}
+RT_DEV EnvironmentSample sample_environment(const DevEnv &e, uint32_t &rng)
+{
+    const EnvironmentPick p = sample_environment_begin(e, rng);
+    return sample_environment_finish(e, rng, p);
 }
 
 // ------------------------------------------------------------------ BSDF (shader.wgsl:55-84, 850-1210)
