@@ -356,22 +356,43 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     h.ref = hr & 0x3fffffffu; h.src = hr >> 30;
                 }
                 DBG_ADD(27, (as_u(hit_record(S, h, 0).w) & 3u) == PRIM_TRIANGLE ? 1 : 0); DBG_ADD(31, (as_u(hit_record(S, h, 0).w) & 3u) == PRIM_SPHERE ? 1 : 0);
-                // Memory first: the alias-table gather of this vertex's environment sample (its address needs the RNG word only)
-                // and the cold columns are requested before anything is computed, the pending NEE term unconditionally — a
-                // load under a branch would have to be waited for, with everything else in flight, right here.
-                uint32_t rng = kRngHot ? HOT(H_T, slot) : COLD(C_RNG, slot);
-                const EnvironmentPick pick = sample_environment_begin(P.env, rng);
-                V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
-                V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
-                const V3 nee_prev = v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot));
-                const uint32_t bounce = (kBounceInCt ? (ct >> (CT_SHIFT + RT_FLAT_BOUNCE_SHIFT)) : COLD(C_BOUNCE, slot)) + 1u;
-                hit_barycentrics(S, h, o, d); // not carried through the traversal: the same test gives the same bits
-                const Surface surf = resolve_hit(S, h, o, d);
-                const BsdfMaterial mat = load_material(S, surf.material_id);
-                const EnvironmentSample es = sample_environment_finish(P.env, rng, pick);
-                // the previous vertex's NEE term, lit: :1246-1249 of the previous iteration
-                if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + nee_prev;
-                Lr = Lr + T * mat.emission;
+                uint32_t rng, bounce;
+                V3 T, Lr;
+                Surface surf;
+                BsdfMaterial mat;
+                EnvironmentSample es;
+                if constexpr (kRngHot) {
+                    // Memory first: the alias-table gather of this vertex's environment sample (its address needs the RNG word
+                    // only, and that is an LDS read away) and the cold columns are requested before anything is computed,
+                    // the pending NEE term unconditionally — a load under a branch would have to be waited for, with
+                    // everything else in flight, right here.  (Not for the walks: their RNG word is one of the cold loads,
+                    // and the longer live ranges push the 128-register kernel into scratch — measured 4 % slower.)
+                    rng = HOT(H_T, slot);
+                    const EnvironmentPick pick = sample_environment_begin(P.env, rng);
+                    T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
+                    Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
+                    const V3 nee_prev = v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot));
+                    bounce = (kBounceInCt ? (ct >> (CT_SHIFT + RT_FLAT_BOUNCE_SHIFT)) : COLD(C_BOUNCE, slot)) + 1u;
+                    hit_barycentrics(S, h, o, d); // not carried through the traversal: the same test gives the same bits
+                    surf = resolve_hit(S, h, o, d);
+                    mat = load_material(S, surf.material_id);
+                    es = sample_environment_finish(P.env, rng, pick);
+                    // the previous vertex's NEE term, lit: :1246-1249 of the previous iteration
+                    if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + nee_prev;
+                    Lr = Lr + T * mat.emission;
+                } else {
+                    hit_barycentrics(S, h, o, d); // not carried through the traversal: the same test gives the same bits
+                    rng = COLD(C_RNG, slot);
+                    T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
+                    Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
+                    bounce = (kBounceInCt ? (ct >> (CT_SHIFT + RT_FLAT_BOUNCE_SHIFT)) : COLD(C_BOUNCE, slot)) + 1u;
+                    // the previous vertex's NEE term, lit: :1246-1249 of the previous iteration
+                    if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot));
+                    surf = resolve_hit(S, h, o, d);
+                    mat = load_material(S, surf.material_id);
+                    Lr = Lr + T * mat.emission;
+                    es = sample_environment(P.env, rng);
+                }
                 const float cos_nee = fmax_(0.0f, dot(surf.normal, es.direction));
                 const bool want_shadow = cos_nee > 0.0f && es.pdf > 0.0f; // a shadow ray is cast: :1246
                 const Frame frame = make_frame(surf.normal); // shader.wgsl:1252 and :1133 build the same frame
