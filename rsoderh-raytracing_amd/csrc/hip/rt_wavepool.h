@@ -15,9 +15,10 @@
 // Where the state lives (measured: run time scales ~linearly with resident waves up to 3 per SIMD, and LDS
 // is what limits them): the HOT columns — what a TRACE invocation needs: the vertex the rays start from,
 // the extension direction, the shadow direction, best t, and one word of tag / flags / traversal cursor —
-// are in LDS, 11 dwords per slot; the COLD columns — throughput, radiance, the pending NEE term, RNG ... —
-// only read / written by the shading stages, are in a global-memory arena (14 dwords per slot, one
-// contiguous column per field and wave, so a stage's accesses coalesce).
+// are in LDS, 11 dwords per slot; the COLD columns — throughput, radiance, the pending NEE term, last pdf ... —
+// only read / written by the shading stages, are in a global-memory arena (14 dwords per slot for the tree
+// walks, 11 for the flat traversal, whose RNG word, bounce count and hit record ride in hot cells that are
+// idle at the time; one contiguous column per field and wave, so a stage's accesses coalesce).
 //
 // Stages: GEN    take the next (pixel, sample) of the wave's chunk, build the camera ray
 //         TRACE  one ray of the slot: its NEE shadow ray first (any hit), then its extension ray (closest hit)
