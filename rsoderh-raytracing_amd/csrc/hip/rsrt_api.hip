@@ -45,7 +45,7 @@ struct RenderParams {
     uint32_t samples_per_chunk, n_sblocks, n_chunks;
     uint32_t chunk_px, n_subtiles; // a chunk covers chunk_px consecutive pixels of a tile (tile_px / n_subtiles)
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
-    uint32_t trace_budget, descend_quorum;
+    uint32_t trace_budget, descend_quorum, flat_quorum;
     uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
     float *sample_buf;
     unsigned int *work_counter;
@@ -325,7 +325,8 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
         DbgCounters dbg;
 #endif
         uint32_t cur = 0, work = 0;
-        while (cur != RT_END) trace_dispatch<(TRAV == 4 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, 50u, cur, h, nullptr, work);
+        unsigned long long flat_rem = 0ull;
+        while (cur != RT_END) trace_dispatch<(TRAV == 4 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, 50u, cur, h, nullptr, work, flat_rem);
         // RSRT_PROBE_REPEAT (tools/trace_rate.py): the same query again and again, so that a timing of this kernel is a timing
         // of the traversal and not of staging the scene for 256 rays; the result does not change
         for (uint32_t k = 1; k < repeat; k++) {
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
             Hit h2;
             h2.t = RT_INFINITY; h2.ref = 0; h2.src = SRC_BVH; h2.u = h2.v = 0.0f;
             cur = 0;
-            while (cur != RT_END) trace_dispatch<(TRAV == 4 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, 50u, cur, h2, nullptr, work);
+            while (cur != RT_END) trace_dispatch<(TRAV == 4 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, 50u, cur, h2, nullptr, work, flat_rem);
             h.t = h2.t; h.ref = h2.ref; h.src = h2.src;
         }
         if (h.did_hit()) hit_barycentrics(S, h, o, d); // as SHADE does: the traversals do not carry u, v
@@ -499,6 +500,7 @@ struct rsrt_context {
     bool allow_hybrid = true;
     uint32_t trace_budget = 0; // traversal steps per TRACE invocation before a ray is re-queued (0: 6 for the fixed-order walk, 12 for the tree walks)
     uint32_t descend_quorum = 30; // fixed-order walk: a descending round ends once fewer than this percentage of its lanes are still descending
+    uint32_t flat_quorum = 0; // flat traversal: the triangle loop ends once fewer than this percentage of its lanes still hold triangles (0: never)
     unsigned long long debug_words[32] = {0};
 };
 
@@ -810,6 +812,7 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     if (const char *fl = getenv("RSRT_FLAT")) ctx->allow_flat = atoi(fl) != 0; // 0: small scenes take the walk a big scene would (A/B)
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
     if (const char *dq = getenv("RSRT_DESCEND_QUORUM")) { int v = atoi(dq); if (v >= 0 && v <= 100) ctx->descend_quorum = (uint32_t)v; }
+    if (const char *fq = getenv("RSRT_FLAT_QUORUM")) { int v = atoi(fq); if (v >= 0 && v <= 100) ctx->flat_quorum = (uint32_t)v; }
     for (int m = 0; m < 15; m++) (void)hipFuncSetAttribute(probe_function(m / 5, m % 5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
     snprintf(buf, sizeof buf, "librsrt 0.1; %s (%s); %d CUs", prop.name, prop.gcnArchName, ctx->cus);
@@ -1389,6 +1392,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.n_slots = P.n_owned_tiles * tile_px;
     P.work_counter = ctx->work_counter;
     P.descend_quorum = ctx->descend_quorum;
+    P.flat_quorum = ctx->flat_quorum;
     P.stats = ctx->dev_stats;
     if (P.n_slots == 0) return RSRT_OK;
 

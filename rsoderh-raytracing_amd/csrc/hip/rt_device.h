@@ -1070,11 +1070,15 @@ RT_DEV uint32_t flat_rank_of(const DevScene &sc, uint32_t octant, uint32_t rec)
 }
 
 template <class View>
-RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V3 inv, bool anyhit, Hit &h)
+RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V3 inv, bool anyhit, uint32_t quorum, uint32_t &cur, unsigned long long &rem, Hit &h)
 {
+    // cur != 0: a ray whose triangle loop was cut short by the vote below comes back with the triangles it has not
+    // tested yet (`rem`) and its best hit so far (`h`); it needs no box test.  A batch of such rays only skips the loop.
+    const bool resumed = cur != 0u;
     uint32_t all_lo = 0u, all_hi = 0u;
+    const uint32_t n_leaves = __ballot(!resumed) != 0ull ? sc.n_leaves : 0u; // (wave-uniform)
 #pragma unroll 1 // (unrolling by 2 or 4 measures the same)
-    for (uint32_t L = 0; L < sc.n_leaves; L++) {
+    for (uint32_t L = 0; L < n_leaves; L++) {
         DBG_WAVE_TICK(10);
         DBG_ADD(11, 1);
         const float4 n0 = S.flat(2u * L), n1 = S.flat(2u * L + 1u);
@@ -1087,7 +1091,7 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
         all_lo |= miss ? 0u : as_u(n0.w); // .w: the leaf's records as a 64-bit mask
         all_hi |= miss ? 0u : as_u(n1.w);
     }
-    const unsigned long long all_m = ((unsigned long long)all_hi << 32) | all_lo;
+    const unsigned long long all_m = resumed ? rem : (((unsigned long long)all_hi << 32) | all_lo);
     const unsigned long long tri_all = ((unsigned long long)sc.tri_mask_hi << 32) | sc.tri_mask_lo;
     const unsigned long long pl_all = ((unsigned long long)sc.plane_mask_hi << 32) | sc.plane_mask_lo;
     unsigned long long tri_m = all_m & tri_all, pl_m = all_m & pl_all, sp_m = all_m & ~(tri_all | pl_all);
@@ -1097,6 +1101,11 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
     if (((t) == h.t) & (h.t < RT_INFINITY)) better = flat_rank_of(sc, octant, (rec)) < flat_rank_of(sc, octant, h.ref); \
     h.t = better ? (t) : h.t;                                                                                          \
     h.ref = better ? (rec) : h.ref;
+    // The vote: rays hold very different numbers of triangles (3.2 on average, 11 for the unluckiest lane of a wave on the
+    // BASELINE scene), and every lane that is through idles until the last one is.  Once fewer than `quorum` percent of the
+    // lanes that entered the loop still hold triangles the wave leaves it; what a lane has not tested goes back to the
+    // scheduler in `rem` (every lane has tested at least one triangle by then, so a ray always advances).
+    const uint32_t tri_started = (uint32_t)__popcll(__ballot(tri_m != 0ull));
     while (tri_m != 0ull) {
         DBG_WAVE_TICK(12);
         DBG_ADD(13, 1);
@@ -1107,7 +1116,9 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
         const float t = triangle_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), u, v);
         RT_FLAT_ACCEPT(t, rec)
         if (better & anyhit) tri_m = pl_m = sp_m = 0ull;
+        if ((uint32_t)__popcll(__ballot(tri_m != 0ull)) * 100u < tri_started * quorum) break; // wave-uniform (quorum 0: never)
     }
+    const unsigned long long tri_left = tri_m; // (the planes and spheres of a ray that is cut short are still tested in this call)
     while (pl_m != 0ull) {
         DBG_WAVE_TICK(15);
         DBG_ADD(13, 1); DBG_ADD(29, 1);
@@ -1129,6 +1140,8 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
         if (better & anyhit) sp_m = 0ull;
     }
 #undef RT_FLAT_ACCEPT
+    rem = (anyhit & (h.t < RT_INFINITY)) ? 0ull : tri_left; // any hit ends a shadow ray, whatever it still holds
+    cur = rem != 0ull ? 1u : RT_END;
 }
 
 // ------------------------------------------------------------------ fixed-order (pre-order) traversal
@@ -1321,15 +1334,14 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
 // (the flat loop, whose work per ray is fixed by the scene, adds nothing).
 template <int TRAV, class View>
 RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t quorum, uint32_t &cur,
-                           Hit &h, const uint32_t *ref_mem, uint32_t &work)
+                           Hit &h, const uint32_t *ref_mem, uint32_t &work, unsigned long long &flat_rem)
 {
     if (TRAV == 2) {
         const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
         // 0 * x is NaN exactly when x is infinite or NaN (an overflowing sum only sends a ray the long way round)
         const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f;
         if (finite == 0.0f) {
-            trace_flat(DBG_ARG S, sc, o, d, inv, anyhit, h);
-            cur = RT_END;
+            trace_flat(DBG_ARG S, sc, o, d, inv, anyhit, quorum, cur, flat_rem, h);
         } else {
             trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, 0xffffffffu, cur, h, work);
         }

@@ -49,20 +49,27 @@ enum CtBits : uint32_t {
 #ifndef RT_RNG_HOT
 #define RT_RNG_HOT 1 // flat traversal: the RNG word travels in the H_T cell instead of a cold column (see the kernel)
 #endif
+#ifndef RT_FLAT_VOTE
+#define RT_FLAT_VOTE 1 // flat traversal: a wave vote may end the triangle loop, the rays cut short are re-queued (needs RT_RNG_HOT, RT_COLD_COMPACT)
+#endif
 enum ColdField {
     C_TX, C_TY, C_TZ, C_LX, C_LY, C_LZ, C_NEEX, C_NEEY, C_NEEZ, C_LASTPDF, C_OUT,
     C_RNG, // (the flat traversal keeps it in a hot cell when RT_RNG_HOT)
     C_BOUNCE,
     C_REF, // tree-walk traversals only: best hit of the extension ray, record | source << 30
     C_COUNT,
-    // the flat traversal stops early: its bounce count and hit record ride in the idle cursor bits of H_CT
-    C_COUNT_FLAT = RT_RNG_HOT ? C_RNG : C_BOUNCE
+    // the flat traversal stops early: its bounce count and hit record ride in the idle cursor bits of H_CT; two columns
+    // hold the untested triangles of a ray whose triangle loop was cut short (RT_FLAT_VOTE; only such rays touch them)
+    C_REM_LO = C_RNG, C_REM_HI = C_BOUNCE,
+    C_COUNT_FLAT = RT_RNG_HOT ? (RT_FLAT_VOTE ? C_REF : C_RNG) : C_BOUNCE
 };
 // RT_COLD_COMPACT=0 restores 14 cold columns for every traversal (A/B of the arena's L2 footprint)
 #ifndef RT_COLD_COMPACT
 #define RT_COLD_COMPACT 1
 #endif
-#define RT_FLAT_BOUNCE_SHIFT 8u     // flat traversal, H_CT payload: hit record (6-bit index | 2-bit source) | bounce << 8
+#define RT_FLAT_BOUNCE_SHIFT 8u     // flat traversal, H_CT payload: hit record (6-bit index | 2-bit source) | bounce << 8 | resumed << 24
+#define RT_FLAT_BOUNCE_BITS 0xffff00u
+#define RT_FLAT_RESUMED (1u << 24)
 #define RT_FLAT_MAX_BOUNCES 0xffffu // 16 bits of the 25; rsrt_render picks a tree-walk kernel beyond that
 __host__ __device__ constexpr uint32_t pool_cold_columns(int trav) { return (RT_COLD_COMPACT && trav == 2) ? (uint32_t)C_COUNT_FLAT : (uint32_t)C_COUNT; }
 enum PoolTag { TAG_FREE = 0, TAG_TRACE = 1, TAG_MISS = 2, TAG_SHADE = 3, TAG_FINISH = 4, TAG_IDLE = 5 };
@@ -138,6 +145,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     // access, the alias-table gather, can leave with the cold loads instead of a memory round trip after them.
     constexpr bool kRngHot = RT_RNG_HOT && TRAV == 2;
     constexpr uint32_t kTCell = kRngHot ? (uint32_t)H_SX : (uint32_t)H_T; // where the extension ray's t waits for SHADE / MISS
+    constexpr bool kFlatVote = RT_FLAT_VOTE && kRngHot && kBounceInCt; // a TRACE call may return a flat traversal unfinished
     const DevScene &sc = P.scene;
     if (SV != 0) stage_scene_lds(sc);
     const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
@@ -274,17 +282,29 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 const V3 d = v3(HOTF(dcol, slot), HOTF(dcol + 1u, slot), HOTF(dcol + 2u, slot));
                 // resume (or start: cur = root, best = INFINITY) the traversal
                 Hit h;
-                uint32_t cur = kBounceInCt ? 0u : (ct >> CT_SHIFT); // (flat: every ray finishes in one call, the bits carry the bounce count)
+                uint32_t cur = kBounceInCt ? (kFlatVote ? (ct >> (CT_SHIFT + 24u)) : 0u) : (ct >> CT_SHIFT); // (flat: the bits carry the bounce count)
+                const uint32_t bounce_bits = kBounceInCt ? ((ct >> CT_SHIFT) & RT_FLAT_BOUNCE_BITS) : 0u;
                 h.src = SRC_BVH;
                 h.t = kRngHot ? RT_INFINITY : HOTF(H_T, slot); h.u = h.v = 0.0f;
+                unsigned long long flat_rem = 0ull;
+                if (kFlatVote && cur != 0u) { // cut short by the vote of an earlier call: the untested triangles, the best hit so far
+                    flat_rem = ((unsigned long long)COLD(C_REM_HI, slot) << 32) | COLD(C_REM_LO, slot);
+                    if (!shadow) h.t = HOTF(kTCell, slot);
+                }
                 // the record of an earlier call's best hit stays in the cold column unless beaten; the fixed-order walk, where
                 // an equal t can still replace it, fetches it from there if (and only if) such a tie comes up
-                h.ref = (TRAV == 3 && !shadow) ? RT_REF_UNKNOWN : 0u;
+                h.ref = (TRAV == 3 && !shadow) ? RT_REF_UNKNOWN : ((kFlatVote && cur != 0u) ? ((ct >> CT_SHIFT) & 63u) : 0u);
                 const float t_in = h.t;
-                trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, P.descend_quorum, cur, h, &COLD(C_REF, slot), n_work);
+                trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, TRAV == 2 ? (kFlatVote ? P.flat_quorum : 0u) : P.descend_quorum,
+                                     cur, h, &COLD(C_REF, slot), n_work, flat_rem);
                 const bool found = TRAV == 3 ? (h.ref != RT_REF_UNKNOWN) : (h.t < t_in); // this call found a closer (or earlier-ranked) hit
                 const bool done = cur == RT_END;
-                if (!done) { // to be resumed: best t and cursor (never the flat traversal)
+                if (!done && kFlatVote) { // flat traversal cut short: the triangles left, best t and record (a shadow ray has none: any hit ends it)
+                    COLD(C_REM_LO, slot) = (uint32_t)flat_rem;
+                    COLD(C_REM_HI, slot) = (uint32_t)(flat_rem >> 32);
+                    if (!shadow) SETH(kTCell, slot, h.t);
+                    SET_CT(slot, RT_FLAT_RESUMED | bounce_bits | (shadow ? 0u : h.ref), ct & CT_FLAGS, TAG_TRACE);
+                } else if (!done) { // to be resumed: best t and cursor
                     if (!kRngHot) SETH(H_T, slot, h.t);
                     if (TRAV != 2 && !shadow && found) COLD(C_REF, slot) = h.ref;
                     SET_CT(slot, cur, ct & CT_FLAGS, TAG_TRACE);
@@ -292,13 +312,13 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     n_shadow++;
                     if (!kRngHot) SETH(H_T, slot, RT_INFINITY); // the extension ray starts fresh
                     const uint32_t fl = (ct & (F_EXT | F_NEE)) | (h.t < RT_INFINITY ? (uint32_t)F_OCCLUDED : 0u);
-                    SET_CT(slot, kBounceInCt ? (ct >> CT_SHIFT) : 0u, fl, (ct & F_EXT) ? TAG_TRACE : TAG_FINISH); // (keeps the bounce bits)
+                    SET_CT(slot, bounce_bits, fl, (ct & F_EXT) ? TAG_TRACE : TAG_FINISH);
                 } else {
                     n_ext++;
                     SETH(kTCell, slot, h.t);
                     if (TRAV != 2 && found) COLD(C_REF, slot) = h.ref;
                     // the flat traversal's records fit the idle cursor bits: no cold column
-                    SET_CT(slot, (TRAV == 2 ? h.ref : 0u) | (kBounceInCt ? (ct >> CT_SHIFT) : 0u), ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
+                    SET_CT(slot, (TRAV == 2 ? h.ref : 0u) | bounce_bits, ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
                 }
             }
         } else if (best == ST_MISS) {
@@ -322,7 +342,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 if (h.did_hit()) { // SHADE takes it from here (and settles the pending NEE term)
                     SETH(kTCell, slot, h.t);
                     if (TRAV == 2) {
-                        SET_CT(slot, h.ref | (h.src << 6) | (kBounceInCt ? (ct >> CT_SHIFT) : 0u), ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
+                        SET_CT(slot, h.ref | (h.src << 6) | (kBounceInCt ? ((ct >> CT_SHIFT) & RT_FLAT_BOUNCE_BITS) : 0u), ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
                     } else {
                         COLD(C_REF, slot) = h.ref | (h.src << 30);
                         SET_CT(slot, 0u, ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
