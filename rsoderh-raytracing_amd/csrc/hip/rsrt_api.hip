@@ -500,7 +500,7 @@ struct rsrt_context {
     bool allow_hybrid = true;
     uint32_t trace_budget = 0; // traversal steps per TRACE invocation before a ray is re-queued (0: 6 for the fixed-order walk, 12 for the tree walks)
     uint32_t descend_quorum = 30; // fixed-order walk: a descending round ends once fewer than this percentage of its lanes are still descending
-    uint32_t flat_quorum = 0; // flat traversal: the triangle loop ends once fewer than this percentage of its lanes still hold triangles (0: never)
+    uint32_t flat_quorum = 20; // flat traversal: the triangle loop ends once fewer than this percentage of its lanes still hold triangles (0: never)
     unsigned long long debug_words[32] = {0};
 };
 

@@ -72,8 +72,13 @@ enum ColdField {
 #define RT_FLAT_RESUMED (1u << 24)
 #define RT_FLAT_MAX_BOUNCES 0xffffu // 16 bits of the 25; rsrt_render picks a tree-walk kernel beyond that
 __host__ __device__ constexpr uint32_t pool_cold_columns(int trav) { return (RT_COLD_COMPACT && trav == 2) ? (uint32_t)C_COUNT_FLAT : (uint32_t)C_COUNT; }
-enum PoolTag { TAG_FREE = 0, TAG_TRACE = 1, TAG_MISS = 2, TAG_SHADE = 3, TAG_FINISH = 4, TAG_IDLE = 5 };
-enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_FINISH = 4, ST_COUNT = 5 };
+enum PoolTag { TAG_FREE = 0, TAG_TRACE = 1, TAG_MISS = 2, TAG_SHADE = 3, TAG_FINISH = 4, TAG_PRIM = 5, TAG_IDLE = 6 };
+// ST_PRIM (flat traversal with RT_FLAT_PRIM_STAGE only): rays whose triangle loop was cut short, scheduled apart from fresh
+// rays so that a batch of them skips the box loop; it runs TRACE's code
+enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_FINISH = 4, ST_PRIM = 5, ST_MAX = 6 };
+#ifndef RT_FLAT_PRIM_STAGE
+#define RT_FLAT_PRIM_STAGE 0 // measured: 28.2 ms per 64 spp at its best quorum (40-50) against 28.0 ms without it at quorum 20; the sixth stage costs the census 1 %
+#endif
 
 template <uint32_t POOL, int TRAV>
 struct PoolLayout {
@@ -84,7 +89,7 @@ struct PoolLayout {
     static constexpr uint32_t kWaveColdDwords = pool_cold_columns(TRAV) * POOL;
 };
 
-RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE, MISS, SHADE, FINISH; IDLE -> ST_COUNT (none)
+RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE, MISS, SHADE, FINISH, PRIM; IDLE -> none
 
 // The lanes of a wave hand data to each other through memory: the compaction list, the hot columns and the stage tag
 // (LDS) and the cold columns (global memory) are written by the lane that runs a stage and read by whichever lane
@@ -146,6 +151,8 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     constexpr bool kRngHot = RT_RNG_HOT && TRAV == 2;
     constexpr uint32_t kTCell = kRngHot ? (uint32_t)H_SX : (uint32_t)H_T; // where the extension ray's t waits for SHADE / MISS
     constexpr bool kFlatVote = RT_FLAT_VOTE && kRngHot && kBounceInCt; // a TRACE call may return a flat traversal unfinished
+    constexpr uint32_t ST_COUNT = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)ST_MAX : (uint32_t)ST_PRIM;
+    constexpr uint32_t kTagCut = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)TAG_PRIM : (uint32_t)TAG_TRACE;
     const DevScene &sc = P.scene;
     if (SV != 0) stage_scene_lds(sc);
     const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         DBG_STAMP(21); // previous stage's tail is charged below; this resets the clock for the census
         // ---------------- 1. census of the stage tags (each lane looks at its kSlotsPerLane slots)
         uint32_t tags[L::kSlotsPerLane];
-        uint32_t count[ST_COUNT] = {0, 0, 0, 0, 0};
+        uint32_t count[ST_COUNT] = {};
         for (uint32_t k = 0; k < L::kSlotsPerLane; k++) {
             tags[k] = (lane + 64u * k < POOL) ? TAG_OF(lane + 64u * k) : (uint32_t)TAG_IDLE;
             const uint32_t st = stage_of_tag(tags[k]);
@@ -217,7 +224,9 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         const uint32_t n_run = min(best_n, 64u);
         const bool on = lane < n_run;
         const uint32_t slot = on ? list[lane] : 0u;
-        if (lane == 0) { DBG_ADD(best, 1); DBG_ADD(5 + best, n_run); }
+        const uint32_t dbg_stage = best == ST_PRIM ? (uint32_t)ST_TRACE : best; // (the diagnostic counters file PRIM under TRACE)
+        (void)dbg_stage;
+        if (lane == 0) { DBG_ADD(dbg_stage, 1); DBG_ADD(5 + dbg_stage, n_run); }
         DBG_STAMP(22); // census + compaction
 
         if (best == ST_GEN) {
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
                     if (lane + 64u * k < POOL && TAG_OF(lane + 64u * k) == TAG_FREE) SET_TAG(lane + 64u * k, TAG_IDLE);
             }
-        } else if (best == ST_TRACE) {
+        } else if (best == ST_TRACE || best == ST_PRIM) {
             // ---------------- TRACE: one ray of the slot from its vertex O — the shadow ray (direction S, any
             // hit) while one is pending, else the extension ray (direction E, closest hit): cast_ray_bvh
             if (on) {
@@ -298,12 +307,13 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, TRAV == 2 ? (kFlatVote ? P.flat_quorum : 0u) : P.descend_quorum,
                                      cur, h, &COLD(C_REF, slot), n_work, flat_rem);
                 const bool found = TRAV == 3 ? (h.ref != RT_REF_UNKNOWN) : (h.t < t_in); // this call found a closer (or earlier-ranked) hit
-                const bool done = cur == RT_END;
+                // (a shadow ray that is cut short with a hit in hand is done whatever the flags say: only did_hit is read)
+                const bool done = cur == RT_END || (kFlatVote && shadow && h.t < RT_INFINITY);
                 if (!done && kFlatVote) { // flat traversal cut short: the triangles left, best t and record (a shadow ray has none: any hit ends it)
                     COLD(C_REM_LO, slot) = (uint32_t)flat_rem;
                     COLD(C_REM_HI, slot) = (uint32_t)(flat_rem >> 32);
                     if (!shadow) SETH(kTCell, slot, h.t);
-                    SET_CT(slot, RT_FLAT_RESUMED | bounce_bits | (shadow ? 0u : h.ref), ct & CT_FLAGS, TAG_TRACE);
+                    SET_CT(slot, RT_FLAT_RESUMED | bounce_bits | (shadow ? 0u : h.ref), ct & CT_FLAGS, kTagCut);
                 } else if (!done) { // to be resumed: best t and cursor
                     if (!kRngHot) SETH(H_T, slot, h.t);
                     if (TRAV != 2 && !shadow && found) COLD(C_REF, slot) = h.ref;
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             }
         }
         RT_WAVE_HANDOVER(); // tags, hot and cold columns: the next census / stage reads them from other lanes
-        DBG_STAMP(16 + best); // the stage just run
+        DBG_STAMP(16 + dbg_stage); // the stage just run
     }
 #undef HOT
 #undef HOTF

@@ -525,7 +525,21 @@ def test_leaves_that_share_records_or_too_many_fallback_records_keep_the_tree_wa
     assert (st2["ext_rays"], st2["shadow_rays"]) == (ost2["ext_rays"], ost2["shadow_rays"])
 
 
-@pytest.mark.parametrize("traversal", ["3", "3-noflat", "1", "0"])
+@pytest.mark.parametrize("quorum", ["0", "20", "60", "100"])
+def test_flat_triangle_vote_does_not_change_the_image(quorum, big_env, monkeypatch):
+    """The flat traversal's triangle loop ends by a wave vote (RSRT_FLAT_QUORUM: once fewer than that percentage of the
+    lanes that entered it still hold triangles); a ray that is cut short is re-queued with the triangles it has not
+    tested and its best hit so far.  Which rays are cut, and how often, must be invisible: 0 never cuts, 100 cuts as
+    soon as the first lane is through."""
+    monkeypatch.setenv("RSRT_FLAT_QUORUM", quorum)
+    sc = R.Scene.load_toml(util.scene_path("house"))
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 160, 90, 0, 4, 8)
+    img, st = gpu_render(sc, big_env, 160, 90, 0, 4, 8)
+    assert np.array_equal(util.bits(img), util.bits(ref))
+    assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+
+
+@pytest.mark.parametrize("traversal", ["3", "3-q100", "3-noflat", "1", "0"])
 def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_env, monkeypatch):
     """Every primitive exists three times, at the same place, with three different materials, so every hit is a
     tie of equal t between records that usually sit in different leaves.  The reference keeps the first one it
@@ -539,6 +553,8 @@ def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_en
     monkeypatch.setenv("RSRT_TRACE_BUDGET", "3")
     if traversal.endswith("noflat"):
         monkeypatch.setenv("RSRT_FLAT", "0")
+    if traversal.endswith("q100"):  # the flat traversal's triangle loop cut as often as can be: ties against the hit of an earlier call
+        monkeypatch.setenv("RSRT_FLAT_QUORUM", "100")
     rng = np.random.default_rng(23)
     mats = np.zeros(3, T.MATERIAL)
     mats["color"] = [[0.9, 0.1, 0.1], [0.1, 0.9, 0.1], [0.1, 0.1, 0.9]]
