@@ -27,8 +27,13 @@
 struct DbgCounters { unsigned long long c[RT_DBG_N]; };
 #define DBG_DECL DbgCounters &dbg,
 #define DBG_ARG dbg,
+#ifdef RT_SHADE_PROFILE // (tools/shade_profile.py) counters 10..15 hold the wave time of SHADE's sections instead of the loop trips
+#define DBG_ADD(i, v) do { if ((i) < 10 || (i) > 15) dbg.c[i] += (v); } while (0)
+#define DBG_WAVE_TICK(i) do { } while (0)
+#else
 #define DBG_ADD(i, v) dbg.c[i] += (v)
 #define DBG_WAVE_TICK(i) do { if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) dbg.c[i] += 1; } while (0)
+#endif
 #else
 #define DBG_DECL
 #define DBG_ARG

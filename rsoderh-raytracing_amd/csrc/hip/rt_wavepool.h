@@ -49,6 +49,9 @@ enum CtBits : uint32_t {
 #ifndef RT_RNG_HOT
 #define RT_RNG_HOT 1 // flat traversal: the RNG word travels in the H_T cell instead of a cold column (see the kernel)
 #endif
+#ifndef RT_GEN_TRACE
+#define RT_GEN_TRACE 1 // flat traversal: GEN traces the camera rays it builds instead of queueing them for TRACE
+#endif
 #ifndef RT_FLAT_VOTE
 #define RT_FLAT_VOTE 1 // flat traversal: a wave vote may end the triangle loop, the rays cut short are re-queued (needs RT_RNG_HOT, RT_COLD_COMPACT)
 #endif
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     constexpr bool kRngHot = RT_RNG_HOT && TRAV == 2;
     constexpr uint32_t kTCell = kRngHot ? (uint32_t)H_SX : (uint32_t)H_T; // where the extension ray's t waits for SHADE / MISS
     constexpr bool kFlatVote = RT_FLAT_VOTE && kRngHot && kBounceInCt; // a TRACE call may return a flat traversal unfinished
+    constexpr bool kGenTrace = RT_GEN_TRACE && kFlatVote; // GEN traces the camera ray it has built
     constexpr uint32_t ST_COUNT = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)ST_MAX : (uint32_t)ST_PRIM;
     constexpr uint32_t kTagCut = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)TAG_PRIM : (uint32_t)TAG_TRACE;
     const DevScene &sc = P.scene;
@@ -195,6 +199,57 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
 #else
 #define DBG_STAMP(i) do { } while (0)
 #endif
+#if defined(RT_INSTRUMENT) && defined(RT_SHADE_PROFILE)
+#define SHADE_STAMP(i) DBG_STAMP(i)
+#else
+#define SHADE_STAMP(i) do { } while (0)
+#endif
+    // One ray of `slot` (tag / flags word `ct`) from o along d, traced or resumed, and what the slot is left as: TRACE's body, as a
+    // lambda because GEN runs it too (RT_GEN_TRACE: a new path's camera ray is traced by the lanes that have just built it).
+    auto trace_slot = [&](const uint32_t slot, const uint32_t ct, const V3 o, const V3 d) __attribute__((always_inline)) {
+        const bool shadow = (ct & F_SHADOW) != 0u;
+        // resume (or start: cur = root, best = INFINITY) the traversal
+        Hit h;
+        uint32_t cur = kBounceInCt ? (kFlatVote ? (ct >> (CT_SHIFT + 24u)) : 0u) : (ct >> CT_SHIFT); // (flat: the bits carry the bounce count)
+        const uint32_t bounce_bits = kBounceInCt ? ((ct >> CT_SHIFT) & RT_FLAT_BOUNCE_BITS) : 0u;
+        h.src = SRC_BVH;
+        h.t = kRngHot ? RT_INFINITY : HOTF(H_T, slot); h.u = h.v = 0.0f;
+        unsigned long long flat_rem = 0ull;
+        if (kFlatVote && cur != 0u) { // cut short by the vote of an earlier call: the untested triangles, the best hit so far
+            flat_rem = ((unsigned long long)COLD(C_REM_HI, slot) << 32) | COLD(C_REM_LO, slot);
+            if (!shadow) h.t = HOTF(kTCell, slot);
+        }
+        // the record of an earlier call's best hit stays in the cold column unless beaten; the fixed-order walk, where
+        // an equal t can still replace it, fetches it from there if (and only if) such a tie comes up
+        h.ref = (TRAV == 3 && !shadow) ? RT_REF_UNKNOWN : ((kFlatVote && cur != 0u) ? ((ct >> CT_SHIFT) & 63u) : 0u);
+        const float t_in = h.t;
+        trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, TRAV == 2 ? (kFlatVote ? P.flat_quorum : 0u) : P.descend_quorum,
+                             cur, h, &COLD(C_REF, slot), n_work, flat_rem);
+        const bool found = TRAV == 3 ? (h.ref != RT_REF_UNKNOWN) : (h.t < t_in); // this call found a closer (or earlier-ranked) hit
+        // (a shadow ray that is cut short with a hit in hand is done whatever the flags say: only did_hit is read)
+        const bool done = cur == RT_END || (kFlatVote && shadow && h.t < RT_INFINITY);
+        if (!done && kFlatVote) { // flat traversal cut short: the triangles left, best t and record (a shadow ray has none: any hit ends it)
+            COLD(C_REM_LO, slot) = (uint32_t)flat_rem;
+            COLD(C_REM_HI, slot) = (uint32_t)(flat_rem >> 32);
+            if (!shadow) SETH(kTCell, slot, h.t);
+            SET_CT(slot, RT_FLAT_RESUMED | bounce_bits | (shadow ? 0u : h.ref), ct & CT_FLAGS, kTagCut);
+        } else if (!done) { // to be resumed: best t and cursor
+            if (!kRngHot) SETH(H_T, slot, h.t);
+            if (TRAV != 2 && !shadow && found) COLD(C_REF, slot) = h.ref;
+            SET_CT(slot, cur, ct & CT_FLAGS, TAG_TRACE);
+        } else if (shadow) {
+            n_shadow++;
+            if (!kRngHot) SETH(H_T, slot, RT_INFINITY); // the extension ray starts fresh
+            const uint32_t fl = (ct & (F_EXT | F_NEE)) | (h.t < RT_INFINITY ? (uint32_t)F_OCCLUDED : 0u);
+            SET_CT(slot, bounce_bits, fl, (ct & F_EXT) ? TAG_TRACE : TAG_FINISH);
+        } else {
+            n_ext++;
+            SETH(kTCell, slot, h.t);
+            if (TRAV != 2 && found) COLD(C_REF, slot) = h.ref;
+            // the flat traversal's records fit the idle cursor bits: no cold column
+            SET_CT(slot, (TRAV == 2 ? h.ref : 0u) | bounce_bits, ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
+        }
+    };
     for (;;) {
         DBG_STAMP(21); // previous stage's tail is charged below; this resets the clock for the census
         // ---------------- 1. census of the stage tags (each lane looks at its kSlotsPerLane slots)
@@ -232,6 +287,8 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         if (best == ST_GEN) {
             // ---------------- GEN: hand out (pixel, sample) items of the wave's chunk
             uint32_t given = 0; // lanes [given, n_run) still need an item
+            bool started = false; // this lane has built a camera ray
+            V3 cam_o = v3(0.0f, 0.0f, 0.0f), cam_d = v3(0.0f, 0.0f, 0.0f);
             while (given < n_run && !exhausted) {
                 if (chunk_left == 0u) {
                     uint32_t c = 0;
@@ -267,7 +324,8 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                         if (!kRngHot) COLD(C_RNG, slot) = ps.rng;
                         if (!kBounceInCt) COLD(C_BOUNCE, slot) = 0u;
                         COLD(C_OUT, slot) = srel * P.n_slots + chunk_tile_slot0 + p;
-                        SET_CT(slot, 0u, F_EXT, TAG_TRACE);
+                        if (kGenTrace) { started = true; cam_o = ps.o; cam_d = ps.d; }
+                        else SET_CT(slot, 0u, F_EXT, TAG_TRACE);
                         n_paths++;
                     }
                     // an out-of-frame pixel of an edge tile: the slot stays FREE and is offered again
@@ -276,6 +334,9 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 chunk_next += take;
                 chunk_left -= take;
             }
+            // the camera rays are traced here and now: the lanes are all busy, the rays of a tile are coherent, and the
+            // path's first trip through the scheduler (a sixth of all its stage switches) is saved
+            if (kGenTrace && started) trace_slot(slot, (uint32_t)F_EXT | (uint32_t)TAG_TRACE, cam_o, cam_d);
             if (exhausted) { // nothing more to hand out: park every FREE slot
                 for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
                     if (lane + 64u * k < POOL && TAG_OF(lane + 64u * k) == TAG_FREE) SET_TAG(lane + 64u * k, TAG_IDLE);
@@ -285,51 +346,10 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             // hit) while one is pending, else the extension ray (direction E, closest hit): cast_ray_bvh
             if (on) {
                 const uint32_t ct = HOT(H_CT, slot);
-                const bool shadow = (ct & F_SHADOW) != 0u;
-                const uint32_t dcol = shadow ? (uint32_t)H_SX : (uint32_t)H_EX;
+                const uint32_t dcol = (ct & F_SHADOW) ? (uint32_t)H_SX : (uint32_t)H_EX;
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
                 const V3 d = v3(HOTF(dcol, slot), HOTF(dcol + 1u, slot), HOTF(dcol + 2u, slot));
-                // resume (or start: cur = root, best = INFINITY) the traversal
-                Hit h;
-                uint32_t cur = kBounceInCt ? (kFlatVote ? (ct >> (CT_SHIFT + 24u)) : 0u) : (ct >> CT_SHIFT); // (flat: the bits carry the bounce count)
-                const uint32_t bounce_bits = kBounceInCt ? ((ct >> CT_SHIFT) & RT_FLAT_BOUNCE_BITS) : 0u;
-                h.src = SRC_BVH;
-                h.t = kRngHot ? RT_INFINITY : HOTF(H_T, slot); h.u = h.v = 0.0f;
-                unsigned long long flat_rem = 0ull;
-                if (kFlatVote && cur != 0u) { // cut short by the vote of an earlier call: the untested triangles, the best hit so far
-                    flat_rem = ((unsigned long long)COLD(C_REM_HI, slot) << 32) | COLD(C_REM_LO, slot);
-                    if (!shadow) h.t = HOTF(kTCell, slot);
-                }
-                // the record of an earlier call's best hit stays in the cold column unless beaten; the fixed-order walk, where
-                // an equal t can still replace it, fetches it from there if (and only if) such a tie comes up
-                h.ref = (TRAV == 3 && !shadow) ? RT_REF_UNKNOWN : ((kFlatVote && cur != 0u) ? ((ct >> CT_SHIFT) & 63u) : 0u);
-                const float t_in = h.t;
-                trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, TRAV == 2 ? (kFlatVote ? P.flat_quorum : 0u) : P.descend_quorum,
-                                     cur, h, &COLD(C_REF, slot), n_work, flat_rem);
-                const bool found = TRAV == 3 ? (h.ref != RT_REF_UNKNOWN) : (h.t < t_in); // this call found a closer (or earlier-ranked) hit
-                // (a shadow ray that is cut short with a hit in hand is done whatever the flags say: only did_hit is read)
-                const bool done = cur == RT_END || (kFlatVote && shadow && h.t < RT_INFINITY);
-                if (!done && kFlatVote) { // flat traversal cut short: the triangles left, best t and record (a shadow ray has none: any hit ends it)
-                    COLD(C_REM_LO, slot) = (uint32_t)flat_rem;
-                    COLD(C_REM_HI, slot) = (uint32_t)(flat_rem >> 32);
-                    if (!shadow) SETH(kTCell, slot, h.t);
-                    SET_CT(slot, RT_FLAT_RESUMED | bounce_bits | (shadow ? 0u : h.ref), ct & CT_FLAGS, kTagCut);
-                } else if (!done) { // to be resumed: best t and cursor
-                    if (!kRngHot) SETH(H_T, slot, h.t);
-                    if (TRAV != 2 && !shadow && found) COLD(C_REF, slot) = h.ref;
-                    SET_CT(slot, cur, ct & CT_FLAGS, TAG_TRACE);
-                } else if (shadow) {
-                    n_shadow++;
-                    if (!kRngHot) SETH(H_T, slot, RT_INFINITY); // the extension ray starts fresh
-                    const uint32_t fl = (ct & (F_EXT | F_NEE)) | (h.t < RT_INFINITY ? (uint32_t)F_OCCLUDED : 0u);
-                    SET_CT(slot, bounce_bits, fl, (ct & F_EXT) ? TAG_TRACE : TAG_FINISH);
-                } else {
-                    n_ext++;
-                    SETH(kTCell, slot, h.t);
-                    if (TRAV != 2 && found) COLD(C_REF, slot) = h.ref;
-                    // the flat traversal's records fit the idle cursor bits: no cold column
-                    SET_CT(slot, (TRAV == 2 ? h.ref : 0u) | bounce_bits, ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
-                }
+                trace_slot(slot, ct, o, d);
             }
         } else if (best == ST_MISS) {
             // ---------------- MISS: brute-force fallback of cast_ray (shader.wgsl:583-598), then escape
@@ -404,10 +424,13 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
                     const V3 nee_prev = v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot));
                     bounce = (kBounceInCt ? (ct >> (CT_SHIFT + RT_FLAT_BOUNCE_SHIFT)) : COLD(C_BOUNCE, slot)) + 1u;
+                    SHADE_STAMP(10);
                     hit_barycentrics(S, h, o, d); // not carried through the traversal: the same test gives the same bits
                     surf = resolve_hit(S, h, o, d);
                     mat = load_material(S, surf.material_id);
+                    SHADE_STAMP(11);
                     es = sample_environment_finish(P.env, rng, pick);
+                    SHADE_STAMP(12);
                     // the previous vertex's NEE term, lit: :1246-1249 of the previous iteration
                     if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + nee_prev;
                     Lr = Lr + T * mat.emission;
@@ -438,7 +461,9 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     const float w = power_heuristic(es.pdf, pdf_bsdf);
                     nee = T * w * es.radiance * scattering * cos_nee / es.pdf;
                 }
+                SHADE_STAMP(13);
                 const BsdfSample bs = bsdf_sample_in_frame(d, surf.normal, frame, wo, mat, rng);
+                SHADE_STAMP(14);
                 bool finished = false, nee_counts = want_shadow;
                 if (bs.dir.x == 0.0f && bs.dir.y == 0.0f && bs.dir.z == 0.0f) {
                     Lr = bs.scattering; // the shader's debug colours overwrite the radiance, NEE term included
