@@ -50,7 +50,7 @@ enum CtBits : uint32_t {
 #define RT_RNG_HOT 1 // flat traversal: the RNG word travels in the H_T cell instead of a cold column (see the kernel)
 #endif
 #ifndef RT_GEN_TRACE
-#define RT_GEN_TRACE 1 // flat traversal: GEN traces the camera rays it builds instead of queueing them for TRACE
+#define RT_GEN_TRACE 1 // GEN traces the camera rays it builds (a first round of them, for the walks) instead of queueing them for TRACE
 #endif
 #ifndef RT_FLAT_VOTE
 #define RT_FLAT_VOTE 1 // flat traversal: a wave vote may end the triangle loop, the rays cut short are re-queued (needs RT_RNG_HOT, RT_COLD_COMPACT)
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     constexpr bool kRngHot = RT_RNG_HOT && TRAV == 2;
     constexpr uint32_t kTCell = kRngHot ? (uint32_t)H_SX : (uint32_t)H_T; // where the extension ray's t waits for SHADE / MISS
     constexpr bool kFlatVote = RT_FLAT_VOTE && kRngHot && kBounceInCt; // a TRACE call may return a flat traversal unfinished
-    constexpr bool kGenTrace = RT_GEN_TRACE && kFlatVote; // GEN traces the camera ray it has built
+    constexpr bool kGenTrace = RT_GEN_TRACE != 0 && TRAV >= 2; // GEN traces the camera ray it has built (the near-first tree walks, kept for RSRT_FLAG_PRUNE, would spill)
     constexpr uint32_t ST_COUNT = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)ST_MAX : (uint32_t)ST_PRIM;
     constexpr uint32_t kTagCut = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)TAG_PRIM : (uint32_t)TAG_TRACE;
     const DevScene &sc = P.scene;
