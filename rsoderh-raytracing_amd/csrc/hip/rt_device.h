@@ -492,27 +492,43 @@ RT_DEV uint32_t clamp_texel(float f, uint32_t n)
 }
 // textureSampleLevel(env, sampler, uv, 0).xyz — linear magnification, clamp-to-edge
 // (src/state.rs:134-142), full-precision f32 weights a*(1-f) + b*f
-RT_DEV V3 sample_env_bilinear(const DevEnv &e, float u, float v)
+// (in two halves, so that a caller can put work between the four gathers and their use)
+struct EnvBilinearFetch {
+    float4 t00, t10, t01, t11;
+    float fx, fy;
+};
+RT_DEV EnvBilinearFetch sample_env_bilinear_begin(const DevEnv &e, float u, float v)
 {
     float x = u * e.wf - 0.5f, y = v * e.hf - 0.5f;
     float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
-    float fx = x - xf, fy = y - yf;
+    EnvBilinearFetch b;
+    b.fx = x - xf; b.fy = y - yf;
     uint32_t x0 = clamp_texel(xf, e.width), x1 = clamp_texel(xf + 1.0f, e.width);
     uint32_t y0 = clamp_texel(yf, e.height), y1 = clamp_texel(yf + 1.0f, e.height);
-    float4 t00 = env_texel(e, (size_t)y0 * e.width + x0), t10 = env_texel(e, (size_t)y0 * e.width + x1);
-    float4 t01 = env_texel(e, (size_t)y1 * e.width + x0), t11 = env_texel(e, (size_t)y1 * e.width + x1);
-    float gx = 1.0f - fx, gy = 1.0f - fy;
-    V3 top = v3(t00.x, t00.y, t00.z) * gx + v3(t10.x, t10.y, t10.z) * fx;
-    V3 bot = v3(t01.x, t01.y, t01.z) * gx + v3(t11.x, t11.y, t11.z) * fx;
-    return top * gy + bot * fy;
+    b.t00 = env_texel(e, (size_t)y0 * e.width + x0); b.t10 = env_texel(e, (size_t)y0 * e.width + x1);
+    b.t01 = env_texel(e, (size_t)y1 * e.width + x0); b.t11 = env_texel(e, (size_t)y1 * e.width + x1);
+    return b;
 }
-RT_DEV float environment_direction_pdf(const DevEnv &e, V3 dir, float u, float v) // :753-769 (uv already computed)
+RT_DEV V3 sample_env_bilinear_finish(const EnvBilinearFetch &b)
+{
+    float gx = 1.0f - b.fx, gy = 1.0f - b.fy;
+    V3 top = v3(b.t00.x, b.t00.y, b.t00.z) * gx + v3(b.t10.x, b.t10.y, b.t10.z) * b.fx;
+    V3 bot = v3(b.t01.x, b.t01.y, b.t01.z) * gx + v3(b.t11.x, b.t11.y, b.t11.z) * b.fx;
+    return top * gy + bot * b.fy;
+}
+RT_DEV V3 sample_env_bilinear(const DevEnv &e, float u, float v) { return sample_env_bilinear_finish(sample_env_bilinear_begin(e, u, v)); }
+// environment_direction_pdf, :753-769 (uv already computed), likewise: the probability mass of the texel under (u, v) ...
+RT_DEV float environment_direction_pmf(const DevEnv &e, float u, float v)
 {
     uint32_t x = min(f2u(u * e.wf), e.width - 1u);
     uint32_t y = min(f2u(v * e.hf), e.height - 1u);
     uint32_t index = x + y * e.width;
-    float pmf = as_f(env_alias(e, index).z);
-    return pmf / environment_pixel_solid_angle(v, e);
+    return as_f(env_alias(e, index).z);
+}
+// ... and the density it stands for
+RT_DEV float environment_direction_pdf(const DevEnv &e, V3 dir, float u, float v)
+{
+    return environment_direction_pmf(e, u, v) / environment_pixel_solid_angle(v, e);
 }
 struct EnvironmentSample {
     V3 direction, radiance;

@@ -357,6 +357,18 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 const uint32_t ct = HOT(H_CT, slot);
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
                 const V3 d = v3(HOTF(H_EX, slot), HOTF(H_EY, slot), HOTF(H_EZ, slot));
+                // Memory first, as in SHADE: what the escape needs — four texels, the alias entry of the texel under the ray, the
+                // cold columns — depends on the ray alone and is asked for before the fallback loops, not after them.  (A ray
+                // that does hit a fallback primitive has asked in vain: no scene the reference ships has one outside its BVH.)
+                float env_u, env_v;
+                direction_to_equirectangular_uv(d, env_u, env_v);
+                const EnvBilinearFetch sky_fetch = sample_env_bilinear_begin(P.env, env_u, env_v);
+                const float sky_pmf = environment_direction_pmf(P.env, env_u, env_v);
+                const float last_pdf = COLDF(C_LASTPDF, slot);
+                const V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
+                V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
+                const V3 nee_prev = v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot));
+                const uint32_t out_slot = COLD(C_OUT, slot);
                 Hit h;
                 h.t = RT_INFINITY; h.ref = 0; h.src = SRC_BVH; h.u = h.v = 0.0f;
                 for (uint32_t i = 0; i < sc.n_spheres; i++) {
@@ -378,16 +390,12 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                         SET_CT(slot, 0u, ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
                     }
                 } else { // escaped: shader.wgsl:1222-1231
-                    float u, v;
-                    direction_to_equirectangular_uv(d, u, v);
-                    const V3 sky = sample_env_bilinear(P.env, u, v);
-                    const float pdf = environment_direction_pdf(P.env, d, u, v);
-                    const float w = power_heuristic(COLDF(C_LASTPDF, slot), pdf);
-                    const V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
-                    V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
-                    if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot)); // previous vertex, lit
+                    const V3 sky = sample_env_bilinear_finish(sky_fetch);
+                    const float pdf = sky_pmf / environment_pixel_solid_angle(env_v, P.env);
+                    const float w = power_heuristic(last_pdf, pdf);
+                    if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + nee_prev; // previous vertex, lit
                     Lr = Lr + T * sky * w;
-                    store_sample(P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u, Lr);
+                    store_sample(P.sample_buf + (size_t)out_slot * 3u, Lr);
                     SET_TAG(slot, TAG_FREE);
                 }
             }
