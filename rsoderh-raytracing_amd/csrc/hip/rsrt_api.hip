@@ -31,6 +31,9 @@
 #define RT_BLOCK 256
 #define RT_STATS_WORDS 40 // paths, ext, shadow, traversal steps + 32 diagnostic words (zero in the product build)
 #define RT_WAVE 64
+#ifndef RT_BIG_POOL
+#define RT_BIG_POOL 192u // RSRT_KERNEL=4: 1024-thread workgroups, this many slots per wave
+#endif
 
 struct RenderParams {
     DevScene scene;
@@ -402,9 +405,11 @@ struct Env {
 } // namespace
 
 // Kernel variants (RSRT_KERNEL): 0 = lockstep megakernel (first kernel); 1, 2, 3 = stage-scheduled wave-pool kernel
-// with 192 / 160 / 128 path slots per wave (160: five workgroups per CU fit in LDS; 128: a smaller path-state arena).
-#define RT_N_VARIANTS 4
-static const uint32_t kVariantPool[RT_N_VARIANTS] = {0, 192, 160, 128};
+// with 192 / 160 / 128 path slots per wave in 256-thread workgroups, each with its own LDS copy of a small scene (160: four
+// workgroups per CU fit in LDS); 4 (default) = for a scene whose whole image fits LDS, ONE 1024-thread workgroup per CU — one
+// scene copy instead of four, which is what makes room for 192 slots per wave (-0.8 % on the BASELINE frame); anything else as 2.
+#define RT_N_VARIANTS 5
+static const uint32_t kVariantPool[RT_N_VARIANTS] = {0, 192, 160, 128, RT_BIG_POOL};
 template <int SV, uint32_t BLOCK, uint32_t POOL>
 static const void *pool_function(int trav)
 {
@@ -422,6 +427,7 @@ static const void *variant_function(int kv, int sv, int trav)
     if (sv == 2) return pool_function<2, 1024, 160>(trav == 2 ? 1 : trav); // (the flat loop needs the whole image: never asked for here)
     if (kv == 1) return sv == 1 ? pool_function<1, RT_BLOCK, 192>(trav) : pool_function<0, RT_BLOCK, 192>(trav);
     if (kv == 3) return sv == 1 ? pool_function<1, RT_BLOCK, 128>(trav) : pool_function<0, RT_BLOCK, 128>(trav);
+    if (kv == 4 && sv == 1) return pool_function<1, 1024, RT_BIG_POOL>(trav);
     return sv == 1 ? pool_function<1, RT_BLOCK, 160>(trav) : pool_function<0, RT_BLOCK, 160>(trav);
 }
 
@@ -494,7 +500,7 @@ struct rsrt_context {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     int blocks_per_cu[12][RT_N_VARIANTS] = {}; // [scene view * 4 + traversal][kernel variant]
-    int kernel_variant = 2; // index into kVariantPool
+    int kernel_variant = 4; // index into kVariantPool
     int max_traversal = 3; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
     bool allow_flat = true;
     bool allow_hybrid = true;
@@ -1421,8 +1427,9 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     // measured on suzanne and the 15 k-triangle grid (profiles/r02_bvh_knobs.txt): with the quorum vote a round is short, and
     // handing the slot back to the scheduler after about one round beats running several rounds with thinning lanes
     P.trace_budget = ctx->trace_budget ? ctx->trace_budget : (trav == 3 ? 6u : 12u);
-    const uint32_t pool = sv == 2 ? 160u : kVariantPool[kv];
-    const uint32_t block = sv == 2 ? 1024u : (uint32_t)RT_BLOCK;
+    const bool big = kv == 4 && sv == 1; // one workgroup per CU shares the scene copy
+    const uint32_t pool = (sv == 2 || (kv == 4 && !big)) ? 160u : kVariantPool[kv];
+    const uint32_t block = (sv == 2 || big) ? 1024u : (uint32_t)RT_BLOCK;
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
                                 : scene_bytes + (size_t)(block / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);

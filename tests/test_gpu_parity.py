@@ -101,9 +101,10 @@ def test_matches_oracle_live(name, w, h, spp, mb, big_env):
     assert (st["paths"], st["ext_rays"], st["shadow_rays"]) == (ost["paths"], ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("variant,traversal", [("0", "3"), ("1", "3"), ("2", "3"), ("3", "3"), ("2", "3-noflat"), ("2", "1"), ("2", "0")])
+@pytest.mark.parametrize("variant,traversal", [("0", "3"), ("1", "3"), ("2", "3"), ("3", "3"), ("4", "3"), ("2", "3-noflat"), ("4", "3-noflat"), ("2", "1"), ("4", "1"), ("2", "0")])
 def test_every_kernel_variant_is_bit_exact(variant, traversal, big_env, monkeypatch):
-    """RSRT_KERNEL: 0 = lockstep megakernel, 1/2/3 = stage-scheduled wave-pool kernel (192/160/128 slots per wave);
+    """RSRT_KERNEL: 0 = lockstep megakernel, 1/2/3 = stage-scheduled wave-pool kernel (192/160/128 slots per wave), 4 (the
+    default) = one 1024-thread workgroup and one scene copy per CU for scenes that fit LDS, 192 slots per wave;
     RSRT_TRAVERSAL caps the traversal: 3 = product (flat loop for small scenes, fixed-order walk otherwise; with
     RSRT_FLAT=0 the fixed-order walk for small scenes too), 1 tree walk with per-type leaf loops, 0 generic tree walk.
     Scheduling differs, the per-path arithmetic does not: all must give the oracle's bits."""

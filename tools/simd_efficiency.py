@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ['RSRT_INSTRUMENT'] = '1'
-os.environ['RSRT_KERNEL'] = sys.argv[1] if len(sys.argv) > 1 else '2'
+os.environ['RSRT_KERNEL'] = sys.argv[1] if len(sys.argv) > 1 else '4'
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 import numpy as np
 import util
