@@ -452,6 +452,9 @@ RT_DEV float environment_pixel_solid_angle(float v, const DevEnv &e) // :739-749
 #ifndef RT_PNODE_GLOBAL_FIRST
 #define RT_PNODE_GLOBAL_FIRST 0
 #endif
+#ifndef RT_FLAT_BOX_UNROLL
+#define RT_FLAT_BOX_UNROLL 4
+#endif
 #ifndef RT_FLAT_TRI_PAIR
 #define RT_FLAT_TRI_PAIR 1 // flat traversal: two triangle records per trip of the triangle loop (-1.2 % on the BASELINE frame)
 #endif
@@ -1101,7 +1104,7 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
     const bool resumed = cur != 0u;
     uint32_t all_lo = 0u, all_hi = 0u;
     const uint32_t n_leaves = __ballot(!resumed) != 0ull ? sc.n_leaves : 0u; // (wave-uniform)
-#pragma unroll 1 // (unrolling by 2 or 4 measures the same)
+#pragma unroll RT_FLAT_BOX_UNROLL // (4: -1.3 % against 1 with the 1024-thread workgroups; it measured the same with 256-thread ones)
     for (uint32_t L = 0; L < n_leaves; L++) {
         DBG_WAVE_TICK(10);
         DBG_ADD(11, 1);
