@@ -5,10 +5,10 @@ import util
 import rsoderh_raytracing_amd as R
 env = R.Environment.synthetic(2048, 1024)
 sc = R.Scene.load_toml(util.scene_path('house'))
-for kv, b in [('2', '5'), ('2', '4'), ('2', '3'), ('2', '2'), ('1', '4'), ('1', '2'), ('0', '8')]:
+for kv, b in [('4', '1'), ('2', '4'), ('3', '4'), ('2', '3'), ('2', '2'), ('4', '1'), ('2', '4')]:
     os.environ['RSRT_BLOCKS_PER_CU'] = b; os.environ['RSRT_KERNEL'] = kv
     st = R.State.new(sc, env, 1920, 1080); st.max_bounces = 10
-    for spp in (1, 4):
+    for spp in (1, 2, 4, 16):
         st.render_range(0, spp); st.synchronize(); st.stats()
         t = time.perf_counter()
         for i in range(50): st.render_range(0, spp)
