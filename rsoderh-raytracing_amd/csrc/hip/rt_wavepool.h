@@ -17,10 +17,12 @@
 // the extension direction, the shadow direction, best t, and one word of tag / flags / traversal cursor —
 // are in LDS, 11 dwords per slot; the COLD columns — throughput, radiance, the pending NEE term, last pdf ... —
 // only read / written by the shading stages, are in a global-memory arena (14 dwords per slot for the tree
-// walks, 11 for the flat traversal, whose RNG word, bounce count and hit record ride in hot cells that are
-// idle at the time; one contiguous column per field and wave, so a stage's accesses coalesce).
+// walks; 11 for the flat traversal, whose RNG word, bounce count and hit record ride in hot cells that are
+// idle at the time, + 2 that only a ray cut short by the triangle-loop vote touches; one contiguous column per
+// field and wave, so a stage's accesses coalesce).
 //
-// Stages: GEN    take the next (pixel, sample) of the wave's chunk, build the camera ray
+// Stages: GEN    take the next (pixel, sample) of the wave's chunk, build the camera ray — and trace it (its first
+//                round, for the walks) then and there: the lanes are all busy and the rays of a tile coherent
 //         TRACE  one ray of the slot: its NEE shadow ray first (any hit), then its extension ray (closest hit)
 //         MISS   the extension ray missed the BVH: cast_ray's brute-force fallback, then the escape
 //         SHADE  everything the shader does at a hit (shader.wgsl:1233-1299): emission, environment sample,
