@@ -339,7 +339,7 @@ RT_DEV float test_record(const View &S, uint32_t rec, uint32_t src, V3 o, V3 d, 
 template <bool ANYHIT, class View>
 RT_DEV void trace_bvh(const View &S, V3 o, V3 d, bool prune, uint32_t *stack, uint32_t stride, Hit &h)
 {
-    V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+    V3 inv = rt_rcp3(d);
     h.t = RT_INFINITY;
     h.ref = 0;
     h.src = SRC_BVH;
@@ -762,7 +762,7 @@ RT_DEV float power_heuristic(float a, float b) // :1206-1210
 template <class View>
 RT_DEV void trace_ww(DBG_DECL const View &S, V3 o, V3 d, bool prune, bool anyhit, uint32_t *stack, uint32_t stride, Hit &h)
 {
-    const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+    const V3 inv = rt_rcp3(d);
     h.t = RT_INFINITY;
     h.ref = 0;
     h.src = SRC_BVH;
@@ -895,7 +895,7 @@ template <class View>
 RT_DEV void trace_threaded(DBG_DECL const View &S, uint32_t n_nodes, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget,
                            uint32_t &cur, Hit &h, uint32_t &work)
 {
-    const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+    const V3 inv = rt_rcp3(d);
     const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
     const uint32_t ebase = octant * n_nodes;
     uint32_t steps = 0;
@@ -984,7 +984,7 @@ RT_DEV void trace_threaded_typed(DBG_DECL const View &S, uint32_t n_nodes, V3 o,
                                  Hit &h, uint32_t &work)
 {
     static_assert(RT_LEAFQ <= 4, "one byte of each 32-bit mask per held leaf");
-    const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+    const V3 inv = rt_rcp3(d);
     const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
     const uint32_t ebase = octant * n_nodes;
     uint32_t steps = 0;
@@ -1228,7 +1228,7 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
                            Hit &h, const uint32_t *ref_mem, uint32_t &work)
 {
     static_assert(RT_LEAFQ >= 2 && RT_LEAFQ <= 4, "one byte of each 32-bit mask per held leaf; the leaf-loop vote rewinds to a second or later leaf");
-    const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+    const V3 inv = rt_rcp3(d);
     const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
     const uint32_t n_elems = sc.n_pnodes;
     uint32_t steps = 0;
@@ -1397,7 +1397,7 @@ RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
                            Hit &h, const uint32_t *ref_mem, uint32_t &work, unsigned long long &flat_rem)
 {
     if (TRAV == 2) {
-        const V3 inv = v3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+        const V3 inv = rt_rcp3(d);
         // 0 * x is NaN exactly when x is infinite or NaN (an overflowing sum only sends a ray the long way round)
         const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f;
         if (finite == 0.0f) {
