@@ -564,6 +564,16 @@ void make_triangle_record(const rsrt_triangle &t, uint32_t index, const rsrt_vec
     r[2] = f4(c[0] - a[0], c[1] - a[1], c[2] - a[2], 0);          // edge_1, :416
     r[3] = f4(0, 0, 0, 0);
 }
+// Do two primitive records put the same numbers into their intersection test (type and geometry words; not the material, not a
+// triangle's normal index)?  Then every ray gets the same t from both.
+bool same_test(const float4 *a, const float4 *b)
+{
+    uint32_t ta, tb;
+    memcpy(&ta, &a[0].w, 4); memcpy(&tb, &b[0].w, 4);
+    if ((ta & 3u) != (tb & 3u) || memcmp(&a[0], &b[0], 12) != 0) return false;
+    if ((ta & 3u) == PRIM_TRIANGLE) return memcmp(&a[1], &b[1], 12) == 0 && memcmp(&a[2], &b[2], 12) == 0;
+    return memcmp(a + 1, b + 1, 3 * sizeof(float4)) == 0;
+}
 // make_bsdf_material / surface_f0 / surface_kd / lobe probabilities (shader.wgsl:850-881, :1147-1148)
 void make_material_record(const rsrt_material &m, float4 *r)
 {
@@ -1134,7 +1144,16 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     if (flat_ok) {
         for (uint32_t i : leaf_nodes) {
             const rsrt_bvh_node &nd = nodes[i];
-            const uint64_t lm = (nd.primitives_len >= 64 ? ~0ull : ((1ull << nd.primitives_len) - 1ull)) << nd.primitives_or_second_child_index;
+            uint64_t lm = (nd.primitives_len >= 64 ? ~0ull : ((1ull << nd.primitives_len) - 1ull)) << nd.primitives_or_second_child_index;
+            // A record whose geometry is bit for bit that of an EARLIER record of the same leaf can never win: it gives the very
+            // same t, and the reference keeps the first of equals (strict <, a leaf's records in index order whatever the
+            // octant).  It is left out of the leaf's mask — house.toml lists its ground plane twice.
+            for (uint32_t b = 1; b < nd.primitives_len; b++)
+                for (uint32_t a = 0; a < b; a++)
+                    if (same_test(p_prims + 4 * (nd.primitives_or_second_child_index + a), p_prims + 4 * (nd.primitives_or_second_child_index + b))) {
+                        lm &= ~(1ull << (nd.primitives_or_second_child_index + b));
+                        break;
+                    }
             p[0] = f4(nd.bounds_min[0], nd.bounds_min[1], nd.bounds_min[2], u2f((uint32_t)lm));
             p[1] = f4(nd.bounds_max[0], nd.bounds_max[1], nd.bounds_max[2], u2f((uint32_t)(lm >> 32)));
             p += 2;
