@@ -548,7 +548,9 @@ def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_en
     winner is visible in the picture.  Exercises the visiting-order ranks of the flat traversal ("3": this scene has
     27 records) and of the fixed-order walk ("3-noflat"), and the position rule of the typed leaf loops; with a
     TRACE budget of 3 steps every traversal is cut and resumed many times, ties against an incumbent of an earlier
-    call included."""
+    call included.  Copies that share a leaf (equal centroids: most do) are the case the flat traversal settles at upload —
+    a record that repeats an EARLIER record of its leaf bit for bit is left out of the leaf's mask, it could never win —
+    so "3" also checks that it is the first copy's material that shows."""
     from rsoderh_raytracing_amd import host, types as T
     monkeypatch.setenv("RSRT_TRAVERSAL", traversal[0])
     monkeypatch.setenv("RSRT_TRACE_BUDGET", "3")
