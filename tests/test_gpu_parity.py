@@ -491,6 +491,57 @@ def test_bvh_whose_boxes_do_not_nest_keeps_the_tree_walk(big_env):
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
+@pytest.mark.parametrize("traversal", ["3", "3-q100", "3-noflat", "1", "0"])
+def test_twin_records_in_different_leaves_tie_by_visiting_order(traversal, big_env, monkeypatch):
+    """A sphere exists twice, with two materials, and its copies sit in DIFFERENT leaves (the builder would never do that — equal
+    centroids share a leaf — so the BVH is edited by hand: the copy is appended to the last leaf, whose box and whose
+    ancestors' boxes grow to hold it).  Every hit on it is a tie of equal t between two leaves; the reference keeps the one it
+    visits first, which depends on the ray's sign octant, and the winner's material shows.  The flat traversal ("3": the octant's
+    tabulated rank; "3-q100": with its triangle loop cut as often as can be), the fixed-order walk and the tree walks must agree
+    with the oracle; the twin may NOT be dropped the way a twin inside one leaf is."""
+    from rsoderh_raytracing_amd import types as T
+    monkeypatch.setenv("RSRT_TRAVERSAL", traversal[0])
+    if traversal.endswith("noflat"):
+        monkeypatch.setenv("RSRT_FLAT", "0")
+    if traversal.endswith("q100"):
+        monkeypatch.setenv("RSRT_FLAT_QUORUM", "100")
+    base = R.Scene.load_toml(util.scene_path("default"))
+    nodes, prims = base.bvh_nodes.copy(), base.primitives
+    k = next(i for i, p in enumerate(prims) if int(p["primitive_type"]) == 0)  # a sphere record ...
+    src = int(prims[k]["index"])
+    last = max((i for i in range(len(nodes)) if nodes[i]["primitives_len"] > 0), key=lambda i: int(nodes[i]["primitives_or_second_child_index"]))
+    assert not (int(nodes[last]["primitives_or_second_child_index"]) <= k < int(nodes[last]["primitives_or_second_child_index"]) + int(nodes[last]["primitives_len"]))  # ... of another leaf
+    spheres = np.zeros(len(base.spheres) + 1, T.SPHERE)  # (np.concatenate would drop the struct's padding)
+    spheres[:-1] = base.spheres
+    spheres[-1] = base.spheres[src]
+    spheres[-1]["material_id"] = (int(spheres[src]["material_id"]) + 1) % len(base.materials)
+    new_prims = np.concatenate([prims, np.array([(0, len(spheres) - 1)], prims.dtype)])
+    lo = np.asarray(spheres[-1]["pos"], np.float32) - np.float32(spheres[-1]["radius"])
+    hi = np.asarray(spheres[-1]["pos"], np.float32) + np.float32(spheres[-1]["radius"])
+    nodes[last]["primitives_len"] += 1
+    parent = {}
+    for i in range(len(nodes)):
+        if nodes[i]["primitives_len"] == 0:
+            parent[i + 1] = i
+            parent[int(nodes[i]["primitives_or_second_child_index"])] = i
+    i = last
+    while True:
+        nodes[i]["bounds_min"] = np.minimum(nodes[i]["bounds_min"], lo)
+        nodes[i]["bounds_max"] = np.maximum(nodes[i]["bounds_max"], hi)
+        if i == 0:
+            break
+        i = parent[i]
+    sc = R.Scene(base.materials, spheres, base.plane_descs, base.vertices, base.normals, base.triangles, base.camera_desc,
+                 planes=base.planes, primitives=new_prims, bvh_nodes=nodes, bvh_depth=base.bvh_depth)
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 128, 80, 0, 4, 10)
+    plain, _ = oracle.render(util.oracle_scene(base), util.oracle_env(big_env), base.camera_uniform().view(oracle.CAMERA), 128, 80, 0, 4, 10)
+    assert not np.array_equal(util.bits(ref), util.bits(plain))  # the twin does win somewhere
+    img, st = gpu_render(sc, big_env, 128, 80, 0, 4, 10)
+    same = util.bits(img) == util.bits(ref)
+    assert same.all(), (traversal, int((~same).any(axis=2).sum()))
+    assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+
+
 def test_leaves_that_share_records_or_too_many_fallback_records_keep_the_tree_walk(big_env):
     """The flat loop carries a hit as a 6-bit record index and gives every record ONE visiting rank.  A foreign BVH
     whose leaves overlap (a record in two leaves: the reference simply tests it twice), or a scene with more than 64
