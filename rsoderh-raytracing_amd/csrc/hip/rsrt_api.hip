@@ -506,6 +506,7 @@ struct rsrt_context {
     bool allow_hybrid = true;
     uint32_t trace_budget = 0; // traversal steps per TRACE invocation before a ray is re-queued (0: 6 for the fixed-order walk, 12 for the tree walks)
     uint32_t descend_quorum = 30; // fixed-order walk: a descending round ends once fewer than this percentage of its lanes are still descending
+    uint32_t chunks_per_wave = 32; // work chunks a resident wave should get at least (RSRT_CHUNKS_PER_WAVE): sets samples per chunk, and sub-tiles for small jobs
     uint32_t flat_quorum = 20; // flat traversal: the triangle loop ends once fewer than this percentage of its lanes still hold triangles (0: never)
     unsigned long long debug_words[32] = {0};
 };
@@ -734,7 +735,7 @@ rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context:
         // where waves run out of work at different times, stays a few percent.
         {
             const uint64_t waves = (uint64_t)ctx->cus * bpc * (block / RT_WAVE);
-            const uint64_t want_chunks = 32ull * waves;
+            const uint64_t want_chunks = (uint64_t)ctx->chunks_per_wave * waves;
             const uint64_t total_tile_samples = (uint64_t)P.n_owned_tiles * P.sample_count;
             uint64_t spc = total_tile_samples / std::max<uint64_t>(want_chunks, 1);
             spc = std::min<uint64_t>(std::max<uint64_t>(spc, 1), std::max<uint32_t>(1u, 2048u / tile_px));
@@ -828,6 +829,7 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     if (const char *fl = getenv("RSRT_FLAT")) ctx->allow_flat = atoi(fl) != 0; // 0: small scenes take the walk a big scene would (A/B)
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
     if (const char *dq = getenv("RSRT_DESCEND_QUORUM")) { int v = atoi(dq); if (v >= 0 && v <= 100) ctx->descend_quorum = (uint32_t)v; }
+    if (const char *cw = getenv("RSRT_CHUNKS_PER_WAVE")) { int v = atoi(cw); if (v >= 1 && v <= 4096) ctx->chunks_per_wave = (uint32_t)v; }
     if (const char *fq = getenv("RSRT_FLAT_QUORUM")) { int v = atoi(fq); if (v >= 0 && v <= 100) ctx->flat_quorum = (uint32_t)v; }
     for (int m = 0; m < 15; m++) (void)hipFuncSetAttribute(probe_function(m / 5, m % 5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
