@@ -149,7 +149,8 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
 {
     typedef PoolLayout<POOL, TRAV> L;
     constexpr bool kBounceInCt = pool_cold_columns(TRAV) == (uint32_t)C_COUNT_FLAT; // no C_BOUNCE / C_REF column
-    // Flat traversal: every ray finishes in one TRACE call, so "best t so far" is INFINITY at every start and the H_T cell is
+    // Flat traversal: a ray finishes in one TRACE call — or is cut short by the triangle-loop vote with its best t parked where the
+    // result would go — so "best t so far" is INFINITY at every fresh start and the H_T cell is
     // only needed for the RESULT of the extension ray — which fits the shadow direction's first cell, dead by then (the
     // shadow ray is traced first).  H_T then carries the RNG word instead of a cold column: SHADE's first dependent memory
     // access, the alias-table gather, can leave with the cold loads instead of a memory round trip after them.
