@@ -7,8 +7,8 @@ Workload (config.workload): assets house.toml, 1920x1080, 256 spp, 8 bounces, sy
 environment (the reference's HDRIs are missing blobs) — BASELINE.json configs[3], the
 configuration `metric` is quoted on.  A step = one complete frame (all 256 samples of every
 pixel) of that workload through the C-ABI, inputs resident in HBM.  With N GPUs the SAME frame is
-partitioned by interleaved 16x16 tiles (one process per GPU) and ONE RCCL reduce(sum) of the accumulators —
-issued by librsrt itself (rsrt_comm_reduce, include/rsrt.h) — brings the frame to rank 0 inside the
+partitioned by interleaved 16x16 tiles (one process per GPU) and ONE RCCL exchange — every rank's own tiles, 1/N of the
+frame, gathered by librsrt itself (rsrt_comm_reduce, include/rsrt.h) — brings the frame to rank 0 inside the
 timed region ("scaling": "strong").  torch.distributed (gloo) is only the control plane: barrier,
 hand-over of the RCCL id, sums of the counters.
 
@@ -382,6 +382,15 @@ def main():
     if world > 1:
         collective = args.collective
         if collective == "rccl":
+            # rsrt_comm_init is a collective (ncclCommInitRank): a rank that cannot even load librccl would return early
+            # while the others block inside it.  So every rank first asks locally (a dlopen, nothing else) and the answers
+            # are combined over gloo; the collective is entered only if ALL ranks can.
+            can = torch.tensor([1 if R.State.comm_available() else 0], dtype=torch.int32)
+            dist.all_reduce(can, op=dist.ReduceOp.MIN)
+            if int(can[0]) == 0:
+                log("librccl cannot be loaded on some rank: falling back to torch.distributed's nccl reduce")
+                collective = "torch-nccl"
+        if collective == "rccl":
             uid, err = [None], ""
             if rank == 0:
                 try:
@@ -424,7 +433,7 @@ def main():
         state.render_range(0, spp, stream=stream.cuda_stream)
         if world > 1:
             if collective == "rccl":
-                state.comm_reduce(0, stream=stream.cuda_stream)  # ONE ncclReduce(sum, f32) of W*H*4 floats over xGMI
+                state.comm_reduce(0, stream=stream.cuda_stream)  # ONE exchange: each rank's tiles (1/N of the frame) to rank 0 over xGMI
             elif collective == "torch-nccl":
                 partition.reduce_accumulators(acc, group=nccl_group)
             else:  # rehearsal: gloo reduces on the host
@@ -502,7 +511,7 @@ def main():
                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                   "config": {"workload": "%s.toml %dx%d %d spp %d bounces, synthetic 2048x1024 HDRI env" % (os.path.basename(args.scene).replace(".toml", ""), W, H, spp, args.bounces),
-                             "parallelism": ("tiles16x16-interleaved x%d, one reduce(sum) per frame via %s" % (world, {"rccl": "librsrt rsrt_comm_reduce (RCCL)", "torch-nccl": "torch.distributed nccl", "gloo": "gloo on the host (rehearsal)"}[collective]))
+                             "parallelism": ("tiles16x16-interleaved-skewed x%d, one exchange per frame via %s" % (world, {"rccl": "librsrt rsrt_comm_reduce (RCCL gather of compact tile buffers)", "torch-nccl": "torch.distributed nccl", "gloo": "gloo on the host (rehearsal)"}[collective]))
                              if world > 1 else "single GPU",
                              "rays_per_frame": rays_total / args.steps, "paths_per_frame": paths_total / args.steps},
                   "ms_per_frame": elapsed / args.steps * 1e3,

@@ -123,9 +123,11 @@ rsrt_status rsrt_environment_build_alias(rsrt_context *ctx, uint32_t slot, rsrt_
                                          uint32_t *leftover_out);
 
 /* -- multi-GPU framebuffer ownership (no reference counterpart) ---------------
- * The frame is cut into tile_w x tile_h pixel tiles numbered row-major; this context renders
- * tile t iff t % world_size == rank and leaves every other pixel of the accumulator untouched.
- * Default: rank 0 of 1 (whole frame). */
+ * The frame is cut into tile_w x tile_h pixel tiles; this context renders tile (tx, ty) iff (tx + ty * skew) % world_size ==
+ * rank — interleaved in x, each tile row shifted by `skew` (the smallest odd number >= 3 coprime to world_size: 3 for 2, 4, 8
+ * GPUs) against the row above, so that a rank's tiles form a lattice whatever the frame width (t % world_size would give every
+ * rank fixed column stripes whenever the tiles per row are a multiple of world_size) — and leaves every other pixel of the
+ * accumulator untouched.  Default: rank 0 of 1 (whole frame). */
 rsrt_status rsrt_set_partition(rsrt_context *ctx, uint32_t rank, uint32_t world_size, uint32_t tile_w, uint32_t tile_h);
 
 /* Pure host arithmetic of that partition (no GPU needed): the rank that renders pixel (x, y) (UINT32_MAX for bad
@@ -133,11 +135,20 @@ rsrt_status rsrt_set_partition(rsrt_context *ctx, uint32_t rank, uint32_t world_
 uint32_t rsrt_partition_owner(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world_size, uint32_t x, uint32_t y);
 rsrt_status rsrt_partition_mask(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world_size,
                                 uint8_t *mask, uint64_t *owned_pixels);
+/* The compact tile buffer the exchange step moves: every rank owns *n_tile_slots = tiles_y * ceil(tiles_x / world_size) tile
+ * slots — the same number for all ranks — of tile_w * tile_h RGBA32F pixels each, row-major inside the tile.  tiles_xy (may be
+ * NULL): 2 words per slot, the tile's (tx, ty), or UINT32_MAX twice for a padding slot (a slot beyond the right edge of the
+ * frame; it holds zeros). */
+rsrt_status rsrt_partition_tiles(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world_size,
+                                 uint32_t *tiles_xy, uint32_t *n_tile_slots);
 
 /* -- multi-GPU, form 1: one process (or thread) per GPU ----------------------------------------
- * The one exchange step of the path — ONE reduce(sum, f32) of the W*H*4 accumulators per frame onto a root — runs on
- * RCCL over xGMI INSIDE the library (librccl is dlopen'ed on first use; a single-GPU caller never needs it).  Every
- * pixel has exactly one non-zero contributor, so the N-GPU frame equals the 1-GPU frame bit for bit.
+ * The one exchange step of the path — the sum of the ranks' W*H*4 accumulators onto a root, once per frame — runs on RCCL
+ * over xGMI INSIDE the library (librccl is dlopen'ed on first use; a single-GPU caller never needs it).  Every pixel has
+ * exactly one owner, so that sum is a GATHER: each rank packs its tiles into the compact buffer above (1 / world of the
+ * frame), the root receives world - 1 of them point to point (grouped ncclSend / ncclRecv) and scatters them into the frame;
+ * nothing is added, and the N-GPU frame equals the 1-GPU frame bit for bit.  (RSRT_COMM_MODE=reduce in the environment:
+ * the dense ncclReduce(sum, f32) of the full accumulators instead, for A/B.)
  *   rank 0:      rsrt_comm_unique_id(&id); hand the 128 bytes to the other ranks (file, socket, MPI, a torch store ...)
  *   every rank:  rsrt_comm_init(ctx, rank, world, &id)   -- creates the communicator (collective call) and sets the tile
  *                                                            partition (rank, world, current tile size)
@@ -146,9 +157,11 @@ rsrt_status rsrt_partition_mask(uint32_t width, uint32_t height, uint32_t tile_w
  * earlier work.  recv_device_rgba32f (root only, ignored elsewhere): where the full frame goes; NULL = in place, i.e.
  * the root's accumulator becomes the full frame (clear it before rendering further samples); a progressive caller
  * passes a separate W*H*4 f32 device buffer so that its accumulator keeps holding only its own tiles.
- * Without rsrt_comm_init the world is one rank and the reduce is a (device) copy or nothing. */
+ * Without rsrt_comm_init the world is one rank and the reduce is a (device) copy or nothing.
+ * N > 1 over RCCL is unverified on hardware so far. */
 #define RSRT_UNIQUE_ID_BYTES 128
 typedef struct rsrt_unique_id { char bytes[RSRT_UNIQUE_ID_BYTES]; } rsrt_unique_id;
+int rsrt_comm_available(void); /* 1: librccl could be loaded (a dlopen, nothing else: safe to ask on every rank BEFORE the collective rsrt_comm_init) */
 rsrt_status rsrt_comm_unique_id(rsrt_unique_id *out); /* error text: rsrt_last_error(NULL) */
 rsrt_status rsrt_comm_init(rsrt_context *ctx, uint32_t rank, uint32_t world_size, const rsrt_unique_id *id);
 rsrt_status rsrt_comm_reduce(rsrt_context *ctx, uint32_t root, void *recv_device_rgba32f, void *hip_stream);
@@ -157,8 +170,8 @@ rsrt_status rsrt_comm_destroy(rsrt_context *ctx); /* also done by rsrt_context_d
 /* -- multi-GPU, form 2: one caller, a list of devices -----------------------
  * What the reference's single-threaded `State` (src/state.rs:60-98 device acquisition, :760-833 render) would bind:
  * one handle over 1/2/4/8 GPUs of the node.  Inside: one rsrt_context per device (rsrt_multi_context gives access,
- * e.g. for per-device stats), ncclCommInitAll, device i renders tiles t % n == i, and the frame is reduced onto
- * devices[0] (grouped ncclReduce into a frame buffer, so the per-device accumulators stay progressive) whenever
+ * e.g. for per-device stats), ncclCommInitAll for a list of two or more, device i renders the tiles of rank i, and the frame
+ * is gathered onto devices[0] (one RCCL group per frame, into a frame buffer, so the per-device accumulators stay progressive) whenever
  * it is asked for.  Calls mirror the single-device ones; errors: rsrt_multi_last_error (NULL handle: of the last
  * failing rsrt_multi_create on this thread). */
 typedef struct rsrt_multi rsrt_multi;
@@ -167,8 +180,9 @@ void rsrt_multi_destroy(rsrt_multi *m);
 const char *rsrt_multi_last_error(const rsrt_multi *m);
 uint32_t rsrt_multi_size(const rsrt_multi *m);
 rsrt_context *rsrt_multi_context(rsrt_multi *m, uint32_t i);
-/* 1: the frame is reduced by RCCL; 0: by peer copies + adds on devices[0] — librccl could not be loaded, or the list names
- * one device twice, which is accepted only with RSRT_MULTI_ALLOW_SAME_DEVICE=1 (a rehearsal of N devices on one GPU). */
+/* 1: the frame is gathered by RCCL; 0: by peer copies of the compact tile buffers onto devices[0] — a list of one device (no
+ * exchange at all), librccl could not be loaded or its communicators did not come up, or the list names one device twice,
+ * which is accepted only with RSRT_MULTI_ALLOW_SAME_DEVICE=1 (a rehearsal of N devices on one GPU). */
 int rsrt_multi_uses_rccl(const rsrt_multi *m);
 rsrt_status rsrt_multi_upload_scene(rsrt_multi *m,
                                     const rsrt_material *materials, uint32_t n_materials,

@@ -98,7 +98,7 @@ def build_hip(force=False, extra_flags=(), instrument=False):
     if knobs:
         flags += knobs
         target = target.replace(".so", "_exp_%s.so" % hashlib.sha256(" ".join(knobs).encode()).hexdigest()[:10])
-    sid = source_id() + ("+" + "+".join(k.lstrip("-D") for k in knobs) if knobs else "") + ("+instr" if instrument else "")
+    sid = source_id() + ("+" + "+".join(k[2:] if k.startswith("-D") else k.lstrip("-") for k in knobs) if knobs else "") + ("+instr" if instrument else "")
     flags.append('-DRSRT_BUILD_ID="%s"' % sid)
     with _locked():
         if force or _newer(target, _deps("hip")):

@@ -45,6 +45,7 @@ struct RenderParams {
     uint32_t sample_begin, sample_count; // of this pass
     uint32_t max_bounces, flags;
     uint32_t tile_w, tile_h, tiles_x, n_tiles, rank, world, n_owned_tiles;
+    uint32_t tiles_per_row, skew; // partition arithmetic, see owned_tile()
     uint32_t samples_per_chunk, n_sblocks, n_chunks;
     uint32_t chunk_px, n_subtiles; // a chunk covers chunk_px consecutive pixels of a tile (tile_px / n_subtiles)
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
@@ -54,6 +55,31 @@ struct RenderParams {
     unsigned int *work_counter;
     unsigned long long *stats; // paths, ext_rays, shadow_rays
 };
+
+// ------------------------------------------------------------------ framebuffer partition
+// The frame is cut into tile_w x tile_h tiles; tile (tx, ty) belongs to rank (tx + ty * skew) % world: interleaved in x, and
+// every row shifted by `skew` against the one above, so that a rank's tiles form a lattice whatever tiles_x is (plain
+// t % world degenerates to fixed column stripes whenever tiles_x is a multiple of world: 1920 / 16 = 120 tiles, 8 GPUs).
+// skew = the smallest odd number >= 3 that has no factor in common with world (3 for 2 / 4 / 8 GPUs).  Every rank owns
+// tiles_per_row = ceil(tiles_x / world) tile slots of every tile row — the same number for all ranks, which is what lets the
+// frame be GATHERED from equally sized compact buffers (rsrt_comm.h); a slot whose tx falls beyond the frame is padding.
+__host__ __device__ inline uint32_t partition_skew(uint32_t world)
+{
+    for (uint32_t s = 3;; s += 2) {
+        uint32_t a = s, b = world;
+        while (b) { const uint32_t t = a % b; a = b; b = t; }
+        if (a == 1u) return s;
+    }
+}
+// rank's j-th tile slot -> tile coordinates; false: a padding slot (nothing to render)
+__host__ __device__ inline bool owned_tile(uint32_t j, uint32_t rank, uint32_t world, uint32_t skew, uint32_t tiles_x, uint32_t tiles_per_row,
+                                           uint32_t &tx, uint32_t &ty)
+{
+    ty = j / tiles_per_row;
+    const uint32_t k = j - ty * tiles_per_row;
+    tx = (rank + world - ((ty % world) * (skew % world)) % world) % world + k * world; // (32-bit: world <= 64)
+    return tx < tiles_x;
+}
 
 template <bool LDS>
 __device__ __forceinline__ SceneView<LDS> make_view(const DevScene &sc);
@@ -158,9 +184,10 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
                 if (c >= P.n_chunks) { exhausted = true; break; }
                 const uint32_t q = c % P.n_subtiles, cb = c / P.n_subtiles; // sub-tile, then (tile, sample block)
                 uint32_t j = cb / P.n_sblocks, b = cb % P.n_sblocks; // owned-tile ordinal, sample block
-                uint32_t t = j * P.world + P.rank;
-                chunk_tx0 = (t % P.tiles_x) * P.tile_w;
-                chunk_ty0 = (t / P.tiles_x) * P.tile_h;
+                uint32_t ttx, tty;
+                if (!owned_tile(j, P.rank, P.world, P.skew, P.tiles_x, P.tiles_per_row, ttx, tty)) continue; // padding slot: next chunk
+                chunk_tx0 = ttx * P.tile_w;
+                chunk_ty0 = tty * P.tile_h;
                 chunk_tile_slot0 = j * tile_px;
                 chunk_s0 = b * P.samples_per_chunk;
                 uint32_t ns = min(P.samples_per_chunk, P.sample_count - chunk_s0);
@@ -289,8 +316,9 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_resolve_kernel(RenderParams P, fl
     if (slot >= P.n_slots) return;
     uint32_t tile_px = P.tile_w * P.tile_h;
     uint32_t j = slot / tile_px, p = slot % tile_px;
-    uint32_t t = j * P.world + P.rank;
-    uint32_t px = (t % P.tiles_x) * P.tile_w + p % P.tile_w, py = (t / P.tiles_x) * P.tile_h + p / P.tile_w;
+    uint32_t ttx, tty;
+    if (!owned_tile(j, P.rank, P.world, P.skew, P.tiles_x, P.tiles_per_row, ttx, tty)) return;
+    uint32_t px = ttx * P.tile_w + p % P.tile_w, py = tty * P.tile_h + p / P.tile_w;
     if (px >= P.width || py >= P.height) return;
     float4 a = accum[(size_t)py * P.width + px];
     const float *src = P.sample_buf + (size_t)slot * 3u;
@@ -496,6 +524,8 @@ struct rsrt_context {
     std::vector<ReduceEvents> pending_reduce;
     double cum_reduce_ms = 0, base_reduce_ms = 0;
     uint32_t cum_reduces = 0;
+    void *comm_buf = nullptr; // compact tile buffers of the exchange step (rsrt_comm.h): one per rank on the root, one elsewhere
+    size_t comm_buf_bytes = 0;
     // scratch for rsrt_resolve_mean_f16 / rsrt_display_srgb8 (grow-only; no per-frame hipMalloc)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -771,6 +801,22 @@ rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context:
     return RSRT_OK;
 }
 
+// the device-only packing of an uploaded environment (rt_alias_device.h, rt_env_pack_*): pmf copies in the texels' alpha and
+// in the alias entries' pad words
+rsrt_status pack_environment(rsrt_context *ctx, Env &e)
+{
+    const size_t n = (size_t)e.width * e.height;
+    rsrt_status st = begin_work(ctx, ctx->stream);
+    if (st) return st;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(rt_env_pack_texels_kernel, dim3(nb), dim3(256), 0, ctx->stream, e.rgba, e.alias, n);
+    hipLaunchKernelGGL(rt_env_pack_alias_kernel, dim3(nb), dim3(256), 0, ctx->stream, e.alias, n);
+    HIP_TRY(ctx, hipGetLastError());
+    if ((st = end_work(ctx, ctx->stream))) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RSRT_OK;
+}
+
 // rsrt_display_srgb8 on any W*H RGBA32F sum that lives on ctx's device (the multi-GPU frame buffer uses it too)
 rsrt_status display_from(rsrt_context *ctx, const float4 *sum, uint32_t sample_total, uint8_t *host_rgba8, size_t n_bytes)
 {
@@ -848,6 +894,7 @@ void rsrt_context_destroy(rsrt_context *ctx)
     for (auto &re : ctx->pending_reduce) { (void)hipEventDestroy(re.begin); (void)hipEventDestroy(re.end); }
     if (ctx->last_event) (void)hipEventDestroy(ctx->last_event);
     (void)hipFree(ctx->scratch);
+    (void)hipFree(ctx->comm_buf);
     for (auto &pe : ctx->pending_events) { (void)hipEventDestroy(pe.begin); (void)hipEventDestroy(pe.traced); (void)hipEventDestroy(pe.end); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->scene_blob);
@@ -1004,7 +1051,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     // ---- fixed-order traversal (rt_device.h, trace_preorder): per-octant visiting rank of EVERY primitive record — the
     // position at which the reference's near-child-first walk meets it — which decides equal t whatever order the records
     // are really tested in; and the skip links of the pre-order node array (next node once an interior node is missed).
-    std::vector<uint32_t> prim_rank(8ull * n_primitives, 0u);
+    std::vector<uint32_t> prim_rank(8ull * n_primitives, 0xffffffffu); // (a record that several leaves share keeps the rank of its FIRST visit: the reference's strict < keeps the first of equals)
     for (uint32_t q = 0; q < 8; q++) {
         std::vector<uint32_t> st{0u};
         uint32_t pos = 0;
@@ -1013,7 +1060,10 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
             st.pop_back();
             const rsrt_bvh_node &nd = nodes[i];
             if (nd.primitives_len != 0) {
-                for (uint32_t k = 0; k < nd.primitives_len; k++) prim_rank[(size_t)q * n_primitives + nd.primitives_or_second_child_index + k] = pos++;
+                for (uint32_t k = 0; k < nd.primitives_len; k++, pos++) {
+                    uint32_t &rk = prim_rank[(size_t)q * n_primitives + nd.primitives_or_second_child_index + k];
+                    rk = std::min(rk, pos);
+                }
             } else {
                 const bool far_first = (q >> nd.split_axis) & 1u;
                 const uint32_t first = i + 1, second = nd.primitives_or_second_child_index;
@@ -1218,6 +1268,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         if (traversal_head_f4 * sizeof(float4) <= 40 * 1024) ctx->hybrid_head_f4 = (uint32_t)traversal_head_f4; // nodes + escape links (tree walks)
         ctx->hybrid_pnode_f4 = 2u * top_elems; // the top block of the fixed-order walk's nodes (all of them when the scene is mid-size)
     }
+    memset(ctx->blocks_per_cu, 0, sizeof ctx->blocks_per_cu); // the kernels' dynamic LDS size depends on the scene: occupancy is asked for again
     ctx->scene_ready = true;
     return RSRT_OK;
 }
@@ -1247,7 +1298,7 @@ rsrt_status rsrt_upload_environment(rsrt_context *ctx, uint32_t slot, uint32_t w
         HIP_TRY(ctx, hipMemcpy(e.alias, alias, n * sizeof(uint4), hipMemcpyHostToDevice));
         e.width = width;
         e.height = height;
-        return RSRT_OK;
+        return pack_environment(ctx, e);
     }
     e.width = width;
     e.height = height;
@@ -1285,17 +1336,17 @@ rsrt_status rsrt_environment_build_alias(rsrt_context *ctx, uint32_t slot, rsrt_
     HIP_TRY(ctx, hipGetLastError());
     uint32_t left = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&left, scalars + 2, 4, hipMemcpyDeviceToHost, q));
-    if (host_out) HIP_TRY(ctx, hipMemcpyAsync(host_out, e.alias, n * sizeof(uint4), hipMemcpyDeviceToHost, q));
+    if (host_out) HIP_TRY(ctx, hipMemcpyAsync(host_out, e.alias, n * sizeof(uint4), hipMemcpyDeviceToHost, q)); // (before the pad words are packed)
     if ((st = end_work(ctx, q))) return st;
     HIP_TRY(ctx, hipStreamSynchronize(q));
     if (leftover_out) *leftover_out = left;
-    return RSRT_OK;
+    return pack_environment(ctx, e);
 }
 
 rsrt_status rsrt_set_partition(rsrt_context *ctx, uint32_t rank, uint32_t world_size, uint32_t tile_w, uint32_t tile_h)
 {
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
-    if (world_size == 0 || rank >= world_size) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "rank %u not in [0,%u)", rank, world_size);
+    if (world_size == 0 || world_size > 65535u || rank >= world_size) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "rank %u not in [0,%u) (or more than 65535 ranks)", rank, world_size);
     if (tile_w == 0 || tile_h == 0 || tile_w * tile_h > 4096 || (tile_w * tile_h) % RT_WAVE != 0)
         return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "tile %ux%u: pixel count must be a multiple of 64 and at most 4096", tile_w, tile_h);
     ctx->rank = rank; ctx->world = world_size; ctx->tile_w = tile_w; ctx->tile_h = tile_h;
@@ -1413,7 +1464,9 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const uint32_t tiles_y = (height + P.tile_h - 1) / P.tile_h;
     P.n_tiles = P.tiles_x * tiles_y;
     P.rank = ctx->rank; P.world = ctx->world;
-    P.n_owned_tiles = P.n_tiles > P.rank ? (P.n_tiles - P.rank + P.world - 1) / P.world : 0;
+    P.skew = partition_skew(P.world);
+    P.tiles_per_row = (P.tiles_x + P.world - 1) / P.world;
+    P.n_owned_tiles = tiles_y * P.tiles_per_row; // tile slots, the same for every rank (some may be padding, see owned_tile)
     const uint32_t tile_px = P.tile_w * P.tile_h;
     if ((uint64_t)P.n_owned_tiles * tile_px > 0x7fffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "frame too large");
     P.n_slots = P.n_owned_tiles * tile_px;

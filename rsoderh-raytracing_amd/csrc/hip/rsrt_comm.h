@@ -1,15 +1,21 @@
 // rsrt_comm.h — multi-GPU behind the C-ABI (included at the end of rsrt_api.hip; see include/rsrt.h, "multi-GPU").
 //
-// The path shards by pixel: tile t of the frame belongs to rank t % world, scene and environment are
-// replicated, and ONE RCCL reduce(sum, f32) of the W*H*4 accumulators per frame brings the image to the root.  Every
-// pixel has exactly one non-zero contributor, so x + 0 + ... + 0 is exact and the N-GPU image equals the 1-GPU image
-// bit for bit whatever order RCCL adds in.  There is no other exchange step, hence no other collective.
+// The path shards by pixel: tile (tx, ty) of the frame belongs to rank (tx + ty * skew) % world (owned_tile,
+// rsrt_api.hip), scene and environment are replicated, and ONE exchange step per frame brings the image to the root.  Every
+// pixel has exactly one owner, so the sum of the ranks' accumulators — x + 0 + ... + 0 — is a GATHER of every rank's own
+// tiles: each rank packs them into a compact buffer (1 / world of the frame: 16.6 MB instead of 133 MB per rank at 4K on 8
+// GPUs), the root receives world - 1 of them (grouped ncclSend / ncclRecv, point to point over xGMI) and scatters them into
+// the frame.  No addition happens, so the N-GPU image equals the 1-GPU image bit for bit by construction.  The dense
+// ncclReduce(sum, f32) of the W*H*4 accumulators that round 2 used is kept behind RSRT_COMM_MODE=reduce for A/B.  There is
+// no other exchange step, hence no other collective.
+// N > 1 over RCCL has not run on hardware yet (one-GPU boxes; RCCL refuses two ranks on one device): the peer-copy form of
+// the same gather runs lists of 2 / 3 / 8 "devices" on one GPU, and the world-2/4/8 tests are the gate wherever GPUs are.
 //
 // Two forms, one implementation:
 //   rsrt_comm_*   one process (or thread) per GPU: rank 0 makes a 128-byte id (rsrt_comm_unique_id), hands it to the
 //                 other ranks by whatever channel the host has, every rank calls rsrt_comm_init on its own context.
 //   rsrt_multi_*  one single-threaded caller, a LIST of devices — what the reference's `State` (src/state.rs:60-98,
-//                 :760-833) would bind: one rsrt_context per device inside, ncclCommInitAll, grouped ncclReduce.
+//                 :760-833) would bind: one rsrt_context per device inside, ncclCommInitAll, one RCCL group per frame.
 //
 // RCCL is loaded lazily with dlopen (librccl.so.1): a single-GPU user never needs it, and a process that already
 // has an RCCL (torch's) gets that same copy instead of a second one.
@@ -27,6 +33,8 @@ struct RcclApi {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -52,7 +60,7 @@ RcclApi &rccl()
 #define RSRT_SYM(name)                                                                     \
     api.name = reinterpret_cast<decltype(api.name)>(dlsym(h, "nccl" #name));               \
     if (!api.name) { api.error = "librccl: symbol nccl" #name " not found"; return; }
-        RSRT_SYM(GetUniqueId) RSRT_SYM(CommInitRank) RSRT_SYM(CommInitAll) RSRT_SYM(CommDestroy) RSRT_SYM(Reduce)
+        RSRT_SYM(GetUniqueId) RSRT_SYM(CommInitRank) RSRT_SYM(CommInitAll) RSRT_SYM(CommDestroy) RSRT_SYM(Reduce) RSRT_SYM(Send) RSRT_SYM(Recv)
         RSRT_SYM(GroupStart) RSRT_SYM(GroupEnd) RSRT_SYM(GetErrorString) RSRT_SYM(GetVersion)
 #undef RSRT_SYM
         api.ok = true;
@@ -66,16 +74,159 @@ RcclApi &rccl()
         if (r_ != ncclSuccess) return fail(ctx, RSRT_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString(r_)); \
     } while (0)
 
-// rank that renders pixel (x, y): the arithmetic rsrt_render's kernels use (tile t = ty * tiles_x + tx -> t % world)
+// rank that renders pixel (x, y): the arithmetic rsrt_render's kernels use (owned_tile, rsrt_api.hip)
 inline uint32_t tile_owner(uint32_t width, uint32_t tile_w, uint32_t tile_h, uint32_t world, uint32_t x, uint32_t y)
 {
-    const uint32_t tiles_x = (width + tile_w - 1) / tile_w;
-    return ((y / tile_h) * tiles_x + x / tile_w) % world;
+    (void)width;
+    return (x / tile_w + ((y / tile_h) % world) * (partition_skew(world) % world)) % world;
 }
 
 bool partition_args_ok(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world)
 {
-    return width && height && world && tile_w && tile_h && tile_w * tile_h <= 4096 && (tile_w * tile_h) % RT_WAVE == 0;
+    return width && height && world && world <= 65535u && tile_w && tile_h && tile_w * tile_h <= 4096 && (tile_w * tile_h) % RT_WAVE == 0;
+}
+
+// geometry of the compact per-rank tile buffers of a frame
+struct TileGeom {
+    uint32_t width, height, tile_w, tile_h, tiles_x, tiles_y, per_row, skew, world, n_slots; // n_slots: pixels of one rank's compact buffer
+};
+TileGeom tile_geom(const rsrt_context *ctx)
+{
+    TileGeom g;
+    g.width = ctx->acc_w; g.height = ctx->acc_h; g.tile_w = ctx->tile_w; g.tile_h = ctx->tile_h; g.world = ctx->world;
+    g.tiles_x = (g.width + g.tile_w - 1) / g.tile_w;
+    g.tiles_y = (g.height + g.tile_h - 1) / g.tile_h;
+    g.per_row = (g.tiles_x + g.world - 1) / g.world;
+    g.skew = partition_skew(g.world);
+    g.n_slots = g.tiles_y * g.per_row * g.tile_w * g.tile_h;
+    return g;
+}
+
+} // namespace
+
+// rank's tiles of a W x H RGBA32F image -> its compact buffer [tile slot][pixel of the tile] (padding and out-of-frame pixels: 0)
+__global__ void rt_pack_tiles_kernel(TileGeom g, uint32_t rank, const float4 *image, float4 *compact)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= g.n_slots) return;
+    const uint32_t tile_px = g.tile_w * g.tile_h, j = slot / tile_px, p = slot % tile_px;
+    uint32_t tx, ty;
+    float4 v = float4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (owned_tile(j, rank, g.world, g.skew, g.tiles_x, g.per_row, tx, ty)) {
+        const uint32_t px = tx * g.tile_w + p % g.tile_w, py = ty * g.tile_h + p / g.tile_w;
+        if (px < g.width && py < g.height) v = image[(size_t)py * g.width + px];
+    }
+    compact[slot] = v;
+}
+// the compact buffers of ranks [0, world) laid end to end -> the frame (every pixel is written exactly once)
+__global__ void rt_unpack_tiles_kernel(TileGeom g, const float4 *gathered, float4 *frame)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)g.n_slots * g.world) return;
+    const uint32_t rank = (uint32_t)(i / g.n_slots), slot = (uint32_t)(i % g.n_slots);
+    const uint32_t tile_px = g.tile_w * g.tile_h, j = slot / tile_px, p = slot % tile_px;
+    uint32_t tx, ty;
+    if (!owned_tile(j, rank, g.world, g.skew, g.tiles_x, g.per_row, tx, ty)) return;
+    const uint32_t px = tx * g.tile_w + p % g.tile_w, py = ty * g.tile_h + p / g.tile_w;
+    if (px < g.width && py < g.height) frame[(size_t)py * g.width + px] = gathered[i];
+}
+
+namespace {
+
+// grow-only exchange buffer of a context: `world` compact buffers on the root (the gather lands there), one elsewhere
+rsrt_status ensure_comm_buf(rsrt_context *ctx, size_t bytes)
+{
+    if (bytes <= ctx->comm_buf_bytes) return RSRT_OK;
+    rsrt_status st = sync_all(ctx);
+    if (st) return st;
+    if (ctx->comm_buf) { (void)hipFree(ctx->comm_buf); ctx->comm_buf = nullptr; ctx->comm_buf_bytes = 0; }
+    HIP_TRY(ctx, hipMalloc(&ctx->comm_buf, bytes));
+    ctx->comm_buf_bytes = bytes;
+    return RSRT_OK;
+}
+
+// The exchange step in two halves, so that a caller with several communicators (rsrt_multi) can put all the RCCL calls of
+// a frame into ONE group: RCCL enqueues nothing before ncclGroupEnd, so whatever has to come AFTER the collective on the
+// stream — the unpack kernel, the timing event, the context's last_event — is enqueued by the second half.
+struct ExchangeInFlight {
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float4 *recv = nullptr;   // root: where the frame goes
+    bool root = false, dense = false, begun = false;
+};
+
+bool comm_dense()
+{
+    const char *m = getenv("RSRT_COMM_MODE"); // "reduce": the dense W*H*4 ncclReduce of round 2 (A/B on a multi-GPU node)
+    return m && strcmp(m, "reduce") == 0;
+}
+
+// first half: pack this rank's tiles and post its RCCL calls (root: world - 1 receives; others: one send)
+rsrt_status exchange_begin(rsrt_context *ctx, uint32_t root, void *recv_device_rgba32f, hipStream_t stream, ExchangeInFlight &x)
+{
+    DeviceGuard g(ctx->device);
+    if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
+    if (root >= ctx->comm_world) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "comm_reduce: root %u not in [0,%u)", root, ctx->comm_world);
+    if (ctx->comm && (ctx->comm_world != ctx->world || ctx->comm_rank != ctx->rank))
+        return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "comm_reduce: the partition (rank %u of %u) is not the communicator's (%u of %u)", ctx->rank, ctx->world, ctx->comm_rank, ctx->comm_world);
+    x.stream = stream;
+    x.root = ctx->comm_rank == root;
+    x.recv = (x.root && recv_device_rgba32f) ? static_cast<float4 *>(recv_device_rgba32f) : ctx->accum;
+    x.dense = comm_dense();
+    const TileGeom tg = tile_geom(ctx);
+    const size_t seg = (size_t)tg.n_slots * sizeof(float4);
+    rsrt_status st = RSRT_OK;
+    if (ctx->comm && !x.dense && ctx->comm_world > 1 && (st = ensure_comm_buf(ctx, x.root ? seg * tg.world : seg))) return st;
+    if ((st = begin_work(ctx, stream))) return st;
+    x.e0 = get_event(ctx); x.e1 = get_event(ctx);
+    x.begun = true;
+    HIP_TRY(ctx, hipEventRecord(x.e0, stream));
+    if (!ctx->comm || ctx->comm_world == 1) { // a world of one: the frame is the accumulator
+        if (x.recv != ctx->accum) HIP_TRY(ctx, hipMemcpyAsync(x.recv, ctx->accum, (size_t)ctx->acc_w * ctx->acc_h * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+        return RSRT_OK;
+    }
+    ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+    if (x.dense) {
+        RCCL_TRY(ctx, rccl().Reduce(ctx->accum, x.recv, (size_t)ctx->acc_w * ctx->acc_h * 4, ncclFloat, ncclSum, (int)root, comm, stream));
+        return RSRT_OK;
+    }
+    // gather of the compact buffers: each pixel has ONE owner, so "sum of the accumulators" is "every rank's own tiles, side
+    // by side" — 1 / world of the bytes of a dense reduce, point to point over xGMI, and no addition at all
+    float4 *mine = static_cast<float4 *>(ctx->comm_buf) + (x.root ? (size_t)ctx->comm_rank * tg.n_slots : 0);
+    hipLaunchKernelGGL(rt_pack_tiles_kernel, dim3((tg.n_slots + 255) / 256), dim3(256), 0, stream, tg, ctx->comm_rank, ctx->accum, mine);
+    HIP_TRY(ctx, hipGetLastError());
+    if (x.root) {
+        for (uint32_t r = 0; r < ctx->comm_world; r++)
+            if (r != root) RCCL_TRY(ctx, rccl().Recv(static_cast<float4 *>(ctx->comm_buf) + (size_t)r * tg.n_slots, (size_t)tg.n_slots * 4, ncclFloat, (int)r, comm, stream));
+    } else {
+        RCCL_TRY(ctx, rccl().Send(mine, (size_t)tg.n_slots * 4, ncclFloat, (int)root, comm, stream));
+    }
+    return RSRT_OK;
+}
+
+// second half (after ncclGroupEnd when grouped): unpack on the root, timing event, end of the context's chain.  `ok` false:
+// the first half (or the group) failed — the events go back to the pool and the chain is closed.
+rsrt_status exchange_end(rsrt_context *ctx, ExchangeInFlight &x, bool ok)
+{
+    if (!x.begun) return RSRT_OK;
+    DeviceGuard g(ctx->device);
+    hipError_t he = hipSuccess;
+    if (ok && ctx->comm && ctx->comm_world > 1 && !x.dense && x.root) {
+        const TileGeom tg = tile_geom(ctx);
+        const size_t n = (size_t)tg.n_slots * tg.world;
+        hipLaunchKernelGGL(rt_unpack_tiles_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, x.stream, tg, static_cast<const float4 *>(ctx->comm_buf), x.recv);
+        he = hipGetLastError();
+    }
+    if (ok && he == hipSuccess) he = hipEventRecord(x.e1, x.stream);
+    if (!ok || he != hipSuccess) {
+        ctx->event_pool.push_back(x.e0);
+        ctx->event_pool.push_back(x.e1);
+        (void)end_work(ctx, x.stream);
+        return he != hipSuccess ? fail(ctx, RSRT_ERR_HIP, "comm_reduce: %s", hipGetErrorString(he)) : RSRT_OK;
+    }
+    ctx->pending_reduce.push_back({x.e0, x.e1});
+    ctx->cum_reduces++;
+    return end_work(ctx, x.stream);
 }
 
 } // namespace
@@ -104,7 +255,29 @@ rsrt_status rsrt_partition_mask(uint32_t width, uint32_t height, uint32_t tile_w
     return RSRT_OK;
 }
 
+// The compact buffer of `rank`: *n_slots = its tile slots (the same for every rank); tiles_xy (may be NULL) receives 2 words
+// per slot, the tile's (tx, ty), or 0xffffffff twice for a padding slot.  Pixel p of slot j is pixel (tx * tile_w + p % tile_w,
+// ty * tile_h + p / tile_w) of the frame.
+rsrt_status rsrt_partition_tiles(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world_size,
+                                 uint32_t *tiles_xy, uint32_t *n_slots)
+{
+    if (!partition_args_ok(width, height, tile_w, tile_h, world_size) || rank >= world_size || !n_slots) return RSRT_ERR_INVALID_ARGUMENT;
+    const uint32_t tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
+    const uint32_t per_row = (tiles_x + world_size - 1) / world_size, skew = partition_skew(world_size);
+    *n_slots = tiles_y * per_row;
+    if (tiles_xy)
+        for (uint32_t j = 0; j < *n_slots; j++) {
+            uint32_t tx, ty;
+            const bool real = owned_tile(j, rank, world_size, skew, tiles_x, per_row, tx, ty);
+            tiles_xy[2 * j] = real ? tx : 0xffffffffu;
+            tiles_xy[2 * j + 1] = real ? ty : 0xffffffffu;
+        }
+    return RSRT_OK;
+}
+
 // ------------------------------------------------------------------ one process per GPU
+int rsrt_comm_available(void) { return rccl().ok ? 1 : 0; } // (only dlopens librccl: no collective, no GPU work)
+
 rsrt_status rsrt_comm_unique_id(rsrt_unique_id *out)
 {
     if (!out) return fail(nullptr, RSRT_ERR_INVALID_ARGUMENT, "out is NULL");
@@ -145,44 +318,29 @@ rsrt_status rsrt_comm_init(rsrt_context *ctx, uint32_t rank, uint32_t world_size
     ctx->comm_owned = true;
     ctx->comm_rank = rank;
     ctx->comm_world = world_size;
-    return rsrt_set_partition(ctx, rank, world_size, ctx->tile_w, ctx->tile_h); // this rank renders tiles t % world == rank
+    return rsrt_set_partition(ctx, rank, world_size, ctx->tile_w, ctx->tile_h); // this rank renders the tiles owned_tile() gives it
 }
 
-// One ncclReduce(sum, f32) of the W*H*4 accumulator onto `root`.  recv_device_rgba32f (root only; ignored elsewhere):
-// where the full frame goes — NULL = in place, the root's own accumulator becomes the full frame (fine when it is
-// cleared before the next render, as a batch renderer does; a progressive caller passes a separate buffer so that
-// its accumulator keeps holding its own tiles only).
+// The exchange step: the frame — the sum of the ranks' accumulators, i.e. every rank's own tiles — onto `root`.
+// recv_device_rgba32f (root only; ignored elsewhere): where the full frame goes — NULL = in place, the root's own
+// accumulator becomes the full frame (fine when it is cleared before the next render, as a batch renderer does; a
+// progressive caller passes a separate buffer so that its accumulator keeps holding its own tiles only).
+// Every rank packs its tiles into a compact buffer (1 / world of the frame), the root receives world - 1 of them
+// (grouped ncclSend / ncclRecv: point to point, all of the root's xGMI links at once) and scatters them into the frame.
 rsrt_status rsrt_comm_reduce(rsrt_context *ctx, uint32_t root, void *recv_device_rgba32f, void *hip_stream)
 {
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
-    DeviceGuard g(ctx->device);
-    if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
-    if (root >= ctx->comm_world) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "comm_reduce: root %u not in [0,%u)", root, ctx->comm_world);
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
-    const size_t count = (size_t)ctx->acc_w * ctx->acc_h * 4;
-    void *recv = (ctx->comm_rank == root && recv_device_rgba32f) ? recv_device_rgba32f : static_cast<void *>(ctx->accum);
-    rsrt_status st = begin_work(ctx, stream);
-    if (st) return st;
-    hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
-    hipError_t he = hipEventRecord(e0, stream);
-    ncclResult_t nr = ncclSuccess;
-    if (he == hipSuccess) {
-        if (ctx->comm)
-            nr = rccl().Reduce(ctx->accum, recv, count, ncclFloat, ncclSum, (int)root, static_cast<ncclComm_t>(ctx->comm), stream);
-        else if (recv != ctx->accum) // world of one, no communicator: the frame is the accumulator
-            he = hipMemcpyAsync(recv, ctx->accum, count * sizeof(float), hipMemcpyDeviceToDevice, stream);
+    ExchangeInFlight x;
+    const bool grouped = ctx->comm && ctx->comm_world > 1 && !comm_dense(); // the root's receives must be posted together
+    if (grouped && rccl().GroupStart() != ncclSuccess) return fail(ctx, RSRT_ERR_COMM, "ncclGroupStart failed");
+    rsrt_status st = exchange_begin(ctx, root, recv_device_rgba32f, stream, x);
+    if (grouped) {
+        const ncclResult_t r = rccl().GroupEnd();
+        if (r != ncclSuccess && !st) st = fail(ctx, RSRT_ERR_COMM, "ncclGroupEnd failed: %s", rccl().GetErrorString(r));
     }
-    if (he == hipSuccess && nr == ncclSuccess) he = hipEventRecord(e1, stream);
-    if (he != hipSuccess || nr != ncclSuccess) { // nothing pending: the two events go back to the pool
-        ctx->event_pool.push_back(e0);
-        ctx->event_pool.push_back(e1);
-        (void)end_work(ctx, stream);
-        if (nr != ncclSuccess) return fail(ctx, RSRT_ERR_COMM, "ncclReduce failed: %s", rccl().GetErrorString(nr));
-        return fail(ctx, RSRT_ERR_HIP, "comm_reduce: %s", hipGetErrorString(he));
-    }
-    ctx->pending_reduce.push_back({e0, e1});
-    ctx->cum_reduces++;
-    return end_work(ctx, stream);
+    const rsrt_status st2 = exchange_end(ctx, x, st == RSRT_OK);
+    return st ? st : st2;
 }
 
 } // extern "C"
@@ -190,20 +348,10 @@ rsrt_status rsrt_comm_reduce(rsrt_context *ctx, uint32_t root, void *recv_device
 // ------------------------------------------------------------------ one caller, a list of devices
 struct rsrt_multi {
     std::vector<rsrt_context *> ctx;
-    float4 *frame = nullptr; // on device ctx[0]: the reduced W*H RGBA32F sum
-    float4 *stage = nullptr; // on device ctx[0]: landing buffer of the peer-copy reduce (no RCCL)
+    float4 *frame = nullptr; // on device ctx[0]: the W*H RGBA32F sum of the whole frame
     uint32_t frame_w = 0, frame_h = 0;
     std::string error;
 };
-
-// frame += part (the reduce without RCCL; every pixel has one non-zero contributor, so the order does not matter)
-__global__ void rt_add_frame_kernel(float4 *frame, const float4 *part, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 a = frame[i], b = part[i];
-    frame[i] = float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
-}
 
 namespace {
 
@@ -238,52 +386,85 @@ rsrt_status multi_ensure_frame(rsrt_multi *m)
     rsrt_context *c0 = m->ctx[0];
     if (m->frame && m->frame_w == c0->acc_w && m->frame_h == c0->acc_h) return RSRT_OK;
     DeviceGuard g(c0->device);
-    if (m->frame) { (void)hipDeviceSynchronize(); (void)hipFree(m->frame); (void)hipFree(m->stage); m->frame = m->stage = nullptr; }
+    if (m->frame) { (void)hipDeviceSynchronize(); (void)hipFree(m->frame); m->frame = nullptr; }
     if (hipMalloc(&m->frame, (size_t)c0->acc_w * c0->acc_h * sizeof(float4)) != hipSuccess) return mfail(m, RSRT_ERR_OUT_OF_MEMORY, "multi frame buffer", "hipMalloc failed");
-    if (m->ctx.size() > 1 && !c0->comm && hipMalloc(&m->stage, (size_t)c0->acc_w * c0->acc_h * sizeof(float4)) != hipSuccess)
-        return mfail(m, RSRT_ERR_OUT_OF_MEMORY, "multi stage buffer", "hipMalloc failed");
     m->frame_w = c0->acc_w;
     m->frame_h = c0->acc_h;
     return RSRT_OK;
 }
 
-// accumulators of all devices -> m->frame on device 0 (grouped: one launch per device, no deadlock with one caller thread)
+// accumulators of all devices -> m->frame on device 0
 rsrt_status multi_reduce(rsrt_multi *m)
 {
     rsrt_status st = multi_ensure_frame(m);
     if (st) return st;
-    if (m->ctx.size() > 1 && !m->ctx[0]->comm) { // no RCCL (not installed, or the list names one device twice): peer copies + adds on devices[0]
-        rsrt_context *c0 = m->ctx[0];
+    rsrt_context *c0 = m->ctx[0];
+    const size_t n_dev = m->ctx.size();
+    if (n_dev == 1) { // one device: the frame is its accumulator (no communicator exists, none is needed)
         DeviceGuard g(c0->device);
-        const size_t n = (size_t)c0->acc_w * c0->acc_h, bytes = n * sizeof(float4);
+        if ((st = begin_work(c0, c0->stream))) return mfail(m, st, "multi reduce", rsrt_last_error(c0));
+        const hipError_t e = hipMemcpyAsync(m->frame, c0->accum, (size_t)c0->acc_w * c0->acc_h * sizeof(float4), hipMemcpyDeviceToDevice, c0->stream);
+        st = end_work(c0, c0->stream);
+        if (e != hipSuccess) return mfail(m, RSRT_ERR_HIP, "multi reduce", hipGetErrorString(e));
+        return st ? mfail(m, st, "multi reduce", rsrt_last_error(c0)) : RSRT_OK;
+    }
+    if (!c0->comm) { // no RCCL (not installed, failed to come up, or the list names one device twice): peer copies of the compact buffers
+        const TileGeom tg = tile_geom(c0);
+        const size_t seg = (size_t)tg.n_slots * sizeof(float4);
+        { DeviceGuard g(c0->device); if ((st = ensure_comm_buf(c0, seg * tg.world))) return mfail(m, st, "multi reduce", rsrt_last_error(c0)); }
+        for (size_t i = 0; i < n_dev; i++) { // every device packs its own tiles, on its own stream, after its renders
+            rsrt_context *ci = m->ctx[i];
+            DeviceGuard gi(ci->device);
+            float4 *mine = static_cast<float4 *>(c0->comm_buf) + i * tg.n_slots; // device 0 packs straight into the gather buffer
+            if (i != 0) {
+                if ((st = ensure_comm_buf(ci, seg))) return mfail(m, st, "multi reduce", rsrt_last_error(ci));
+                mine = static_cast<float4 *>(ci->comm_buf);
+            }
+            if ((st = begin_work(ci, ci->stream))) return mfail(m, st, "multi reduce", rsrt_last_error(ci));
+            hipLaunchKernelGGL(rt_pack_tiles_kernel, dim3((tg.n_slots + 255) / 256), dim3(256), 0, ci->stream, tg, (uint32_t)i, ci->accum, mine);
+            const hipError_t e = hipGetLastError();
+            st = end_work(ci, ci->stream);
+            if (e != hipSuccess) return mfail(m, RSRT_ERR_HIP, "multi reduce (pack)", hipGetErrorString(e));
+            if (st) return mfail(m, st, "multi reduce", rsrt_last_error(ci));
+        }
+        DeviceGuard g(c0->device);
         hipStream_t q = c0->stream;
         if ((st = begin_work(c0, q))) return mfail(m, st, "multi reduce", rsrt_last_error(c0));
-        hipError_t e = hipMemcpyAsync(m->frame, c0->accum, bytes, hipMemcpyDeviceToDevice, q);
-        for (size_t i = 1; i < m->ctx.size() && e == hipSuccess; i++) {
+        hipError_t e = hipSuccess;
+        for (size_t i = 1; i < n_dev && e == hipSuccess; i++) {
             rsrt_context *ci = m->ctx[i];
-            if (ci->last_valid) e = hipStreamWaitEvent(q, ci->last_event, 0); // after device i's renders
-            if (e == hipSuccess) e = hipMemcpyPeerAsync(m->stage, c0->device, ci->accum, ci->device, bytes, q);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(rt_add_frame_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, q, m->frame, m->stage, n);
-                e = hipGetLastError();
-            }
+            e = hipStreamWaitEvent(q, ci->last_event, 0); // after device i's pack
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(static_cast<float4 *>(c0->comm_buf) + i * tg.n_slots, c0->device, ci->comm_buf, ci->device, seg, q);
+        }
+        if (e == hipSuccess) {
+            const size_t n = (size_t)tg.n_slots * tg.world;
+            hipLaunchKernelGGL(rt_unpack_tiles_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, q, tg, static_cast<const float4 *>(c0->comm_buf), m->frame);
+            e = hipGetLastError();
         }
         if (e != hipSuccess) { (void)end_work(c0, q); return mfail(m, RSRT_ERR_HIP, "multi reduce (peer copies)", hipGetErrorString(e)); }
         if ((st = end_work(c0, q))) return mfail(m, st, "multi reduce", rsrt_last_error(c0));
-        for (size_t i = 1; i < m->ctx.size(); i++) { // device i must not overwrite its accumulator before it has been copied
+        for (size_t i = 1; i < n_dev; i++) { // device i must not pack again before its buffer has been copied
             DeviceGuard gi(m->ctx[i]->device);
             if (hipStreamWaitEvent(m->ctx[i]->stream, c0->last_event, 0) != hipSuccess) return mfail(m, RSRT_ERR_HIP, "multi reduce", "hipStreamWaitEvent failed");
         }
         return RSRT_OK;
     }
-    const bool grouped = m->ctx[0]->comm != nullptr;
-    if (grouped && rccl().GroupStart() != ncclSuccess) return mfail(m, RSRT_ERR_COMM, "multi reduce", "ncclGroupStart failed");
+    // RCCL, one group for the whole list: nothing is enqueued before ncclGroupEnd, so every context's unpack / timing
+    // event / last_event is recorded AFTER it (exchange_end) — a render that follows on another stream waits for the
+    // exchange, not for the stream position in front of it
+    std::vector<ExchangeInFlight> x(n_dev);
+    if (rccl().GroupStart() != ncclSuccess) return mfail(m, RSRT_ERR_COMM, "multi reduce", "ncclGroupStart failed");
     rsrt_status first = RSRT_OK;
-    for (rsrt_context *c : m->ctx) {
-        st = rsrt_comm_reduce(c, 0, m->frame, nullptr);
-        if (st && !first) { first = st; mfail(m, st, "multi reduce", rsrt_last_error(c)); }
+    for (size_t i = 0; i < n_dev; i++) {
+        st = exchange_begin(m->ctx[i], 0, m->frame, m->ctx[i]->stream, x[i]);
+        if (st && !first) { first = st; mfail(m, st, "multi reduce", rsrt_last_error(m->ctx[i])); }
     }
-    if (grouped && rccl().GroupEnd() != ncclSuccess && !first) first = mfail(m, RSRT_ERR_COMM, "multi reduce", "ncclGroupEnd failed");
+    const ncclResult_t r = rccl().GroupEnd();
+    if (r != ncclSuccess && !first) first = mfail(m, RSRT_ERR_COMM, "multi reduce: ncclGroupEnd", rccl().GetErrorString(r));
+    for (size_t i = 0; i < n_dev; i++) {
+        st = exchange_end(m->ctx[i], x[i], first == RSRT_OK);
+        if (st && !first) { first = st; mfail(m, st, "multi reduce", rsrt_last_error(m->ctx[i])); }
+    }
     return first;
 }
 
@@ -300,7 +481,7 @@ void rsrt_multi_destroy(rsrt_multi *m)
 {
     if (!m) return;
     for (rsrt_context *c : m->ctx) (void)rsrt_synchronize(c);
-    if (m->frame && !m->ctx.empty()) { DeviceGuard g(m->ctx[0]->device); (void)hipFree(m->frame); (void)hipFree(m->stage); }
+    if (m->frame && !m->ctx.empty()) { DeviceGuard g(m->ctx[0]->device); (void)hipFree(m->frame); }
     for (rsrt_context *c : m->ctx) rsrt_context_destroy(c); // destroys its communicator too
     delete m;
 }
@@ -328,15 +509,21 @@ rsrt_status rsrt_multi_create(const int *devices, uint32_t n_devices, rsrt_multi
         }
         m->ctx.push_back(c);
     }
-    if (rccl().ok && !duplicates) { // (a list of one device gets a communicator too: the same calls run whatever the list length)
+    // A list of one device needs no communicator (and a single-GPU caller no RCCL at all: librccl is not even loaded).  Should
+    // RCCL be there but fail to bring the communicators up, the list still works: the frame is then brought together by peer
+    // copies of the compact tile buffers (rsrt_multi_uses_rccl() says which).
+    if (n_devices > 1 && !duplicates && rccl().ok) {
         std::vector<ncclComm_t> comms(n_devices);
         const ncclResult_t r = rccl().CommInitAll(comms.data(), (int)n_devices, devices);
-        if (r != ncclSuccess) { mfail(nullptr, RSRT_ERR_COMM, "ncclCommInitAll", rccl().GetErrorString(r)); rsrt_multi_destroy(m); return RSRT_ERR_COMM; }
-        for (uint32_t i = 0; i < n_devices; i++) {
-            m->ctx[i]->comm = comms[i];
-            m->ctx[i]->comm_owned = true;
-            m->ctx[i]->comm_rank = i;
-            m->ctx[i]->comm_world = n_devices;
+        if (r != ncclSuccess) {
+            fprintf(stderr, "librsrt: ncclCommInitAll failed (%s); the frame will be gathered by peer copies instead\n", rccl().GetErrorString(r));
+        } else {
+            for (uint32_t i = 0; i < n_devices; i++) {
+                m->ctx[i]->comm = comms[i];
+                m->ctx[i]->comm_owned = true;
+                m->ctx[i]->comm_rank = i;
+                m->ctx[i]->comm_world = n_devices;
+            }
         }
     }
     for (uint32_t i = 0; i < n_devices; i++) (void)rsrt_set_partition(m->ctx[i], i, n_devices, 16, 16);

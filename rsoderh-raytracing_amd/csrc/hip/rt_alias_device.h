@@ -203,3 +203,20 @@ __global__ void rt_alias_pmf_kernel(const float *p, size_t n, uint4 *out)
     const float nf = (float)n;
     if (out[i].y != (uint32_t)i) out[i].z = as_u(p[i] / nf);
 }
+
+// The packed device layout of an environment (rt_device.h, RT_ENV_PACKED): texel alpha := pmf of the texel's own alias entry,
+// entry pad := pmf of the entry's alias target.  Copies of f32 values the kernels would otherwise gather from a second table.
+// Two passes, because the second reads the z words of OTHER entries.
+__global__ void rt_env_pack_texels_kernel(float4 *rgba, const uint4 *alias, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rgba[i].w = as_f(alias[i].z);
+}
+__global__ void rt_env_pack_alias_kernel(uint4 *alias, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    alias[i].w = alias[alias[i].y].z; // (only .w is written, only .y / .z are read: no race)
+}
+

@@ -502,6 +502,7 @@ RT_DEV uint32_t clamp_texel(float f, uint32_t n)
 struct EnvBilinearFetch {
     float4 t00, t10, t01, t11;
     float fx, fy;
+    uint32_t sel; // (sample_env_bilinear_begin_pmf only) which of the four texels lies under (u, v): bit 0 column x1, bit 1 row y1, bit 2 none of them
 };
 RT_DEV EnvBilinearFetch sample_env_bilinear_begin(const DevEnv &e, float u, float v)
 {
@@ -531,6 +532,36 @@ RT_DEV float environment_direction_pmf(const DevEnv &e, float u, float v)
     uint32_t index = x + y * e.width;
     return as_f(env_alias(e, index).z);
 }
+// Packed environment (device layout only, rt_env_pack_kernel at upload): a texel's alpha — 0 in the reference's texture
+// (src/texture.rs:112-115) and never sampled (`.xyz`, shader.wgsl:825-830) — carries the pmf of that texel's alias entry, and an
+// alias entry's pad word the pmf of its alias TARGET.  An escaping ray's pdf (environment_direction_pdf) then needs no
+// alias-table gather of its own: the texel under (u, v) is one of the four the bilinear fetch reads anyway (floor(p) is
+// floor(p - 0.5) or that + 1, and both sides clamp alike); should it ever not be, the gather is still there.  The same copies
+// of the same f32 values, so the bits cannot change; one 128-byte line request less per escape and per aliased NEE pick.
+#ifndef RT_ENV_PACKED
+#define RT_ENV_PACKED 1
+#endif
+RT_DEV EnvBilinearFetch sample_env_bilinear_begin_pmf(const DevEnv &e, float u, float v)
+{
+    float x = u * e.wf - 0.5f, y = v * e.hf - 0.5f;
+    float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+    EnvBilinearFetch b;
+    b.fx = x - xf; b.fy = y - yf;
+    uint32_t x0 = clamp_texel(xf, e.width), x1 = clamp_texel(xf + 1.0f, e.width);
+    uint32_t y0 = clamp_texel(yf, e.height), y1 = clamp_texel(yf + 1.0f, e.height);
+    b.t00 = env_texel(e, (size_t)y0 * e.width + x0); b.t10 = env_texel(e, (size_t)y0 * e.width + x1);
+    b.t01 = env_texel(e, (size_t)y1 * e.width + x0); b.t11 = env_texel(e, (size_t)y1 * e.width + x1);
+    const uint32_t px = min(f2u(u * e.wf), e.width - 1u), py = min(f2u(v * e.hf), e.height - 1u); // environment_direction_pmf's texel
+    b.sel = (px != x0 ? 1u : 0u) | (py != y0 ? 2u : 0u) | ((((px != x0) & (px != x1)) | ((py != y0) & (py != y1))) ? 4u : 0u);
+    return b;
+}
+RT_DEV float env_bilinear_pmf(const DevEnv &e, const EnvBilinearFetch &b, float u, float v)
+{
+    const float top = (b.sel & 1u) ? b.t10.w : b.t00.w, bot = (b.sel & 1u) ? b.t11.w : b.t01.w;
+    float pmf = (b.sel & 2u) ? bot : top;
+    if (b.sel & 4u) pmf = environment_direction_pmf(e, u, v); // (never taken: see above)
+    return pmf;
+}
 // ... and the density it stands for
 RT_DEV float environment_direction_pdf(const DevEnv &e, V3 dir, float u, float v)
 {
@@ -554,6 +585,9 @@ RT_DEV EnvironmentPick sample_environment_begin(const DevEnv &e, uint32_t &rng) 
     p.entry = env_alias_stream(e, p.index);
     return p;
 }
+// PACKED: the alias target's pmf is read from the entry's pad word instead of the target's own entry (RT_ENV_PACKED; the flat
+// kernel only — the walks have no register left for the fourth word of the entry, tests/test_code_object.py)
+template <bool PACKED = false>
 RT_DEV EnvironmentSample sample_environment_finish(const DevEnv &e, uint32_t &rng, const EnvironmentPick &p) // draws two to four
 {
     const uint32_t index = p.index;
@@ -569,7 +603,9 @@ RT_DEV EnvironmentSample sample_environment_finish(const DevEnv &e, uint32_t &rn
     EnvironmentSample s;
     s.direction = equirectangular_uv_to_direction(u, v);
     s.radiance = sample_env_bilinear(e, u, v);
-    float pmf = (pick == index) ? as_f(entry.z) : as_f(env_alias(e, pick).z);
+    float pmf;
+    if (PACKED) pmf = (pick == index) ? as_f(entry.z) : as_f(entry.w); // .w: the pmf of the alias target (rt_env_pack_alias_kernel)
+    else pmf = (pick == index) ? as_f(entry.z) : as_f(env_alias(e, pick).z);
     s.pdf = pmf / environment_pixel_solid_angle(v, e);
     return s;
 }

@@ -157,6 +157,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     constexpr bool kRngHot = RT_RNG_HOT && TRAV == 2;
     constexpr uint32_t kTCell = kRngHot ? (uint32_t)H_SX : (uint32_t)H_T; // where the extension ray's t waits for SHADE / MISS
     constexpr bool kFlatVote = RT_FLAT_VOTE && kRngHot && kBounceInCt; // a TRACE call may return a flat traversal unfinished
+    constexpr bool kPackedMiss = RT_ENV_PACKED != 0 && TRAV == 2; // MISS reads an escaping ray's pmf from the texels' alpha (rt_device.h)
     constexpr bool kGenTrace = RT_GEN_TRACE != 0 && TRAV >= 2; // GEN traces the camera ray it has built (the near-first tree walks, kept for RSRT_FLAG_PRUNE, would spill)
     constexpr uint32_t ST_COUNT = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)ST_MAX : (uint32_t)ST_PRIM;
     constexpr uint32_t kTagCut = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)TAG_PRIM : (uint32_t)TAG_TRACE;
@@ -300,9 +301,10 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     if (c >= P.n_chunks) { exhausted = true; break; }
                     const uint32_t q = c % P.n_subtiles, cb = c / P.n_subtiles; // sub-tile, then (tile, sample block)
                     const uint32_t j = cb / P.n_sblocks, b = cb % P.n_sblocks;
-                    const uint32_t t = j * P.world + P.rank;
-                    chunk_tx0 = (t % P.tiles_x) * P.tile_w;
-                    chunk_ty0 = (t / P.tiles_x) * P.tile_h;
+                    uint32_t ttx, tty;
+                    if (!owned_tile(j, P.rank, P.world, P.skew, P.tiles_x, P.tiles_per_row, ttx, tty)) continue; // padding slot: next chunk
+                    chunk_tx0 = ttx * P.tile_w;
+                    chunk_ty0 = tty * P.tile_h;
                     chunk_tile_slot0 = j * tile_px;
                     chunk_s0 = b * P.samples_per_chunk;
                     chunk_p0 = q * P.chunk_px;
@@ -365,8 +367,11 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 // that does hit a fallback primitive has asked in vain: no scene the reference ships has one outside its BVH.)
                 float env_u, env_v;
                 direction_to_equirectangular_uv(d, env_u, env_v);
-                const EnvBilinearFetch sky_fetch = sample_env_bilinear_begin(P.env, env_u, env_v);
-                const float sky_pmf = environment_direction_pmf(P.env, env_u, env_v);
+                // (flat kernel: the texel's alpha carries its pmf, no alias-table gather; the walks, a register short of their 128,
+                // keep the gather — tests/test_code_object.py)
+                const EnvBilinearFetch sky_fetch = kPackedMiss ? sample_env_bilinear_begin_pmf(P.env, env_u, env_v) : sample_env_bilinear_begin(P.env, env_u, env_v);
+                float sky_pmf = 0.0f;
+                if (!kPackedMiss) sky_pmf = environment_direction_pmf(P.env, env_u, env_v);
                 const float last_pdf = COLDF(C_LASTPDF, slot);
                 const V3 T = v3(COLDF(C_TX, slot), COLDF(C_TY, slot), COLDF(C_TZ, slot));
                 V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
@@ -394,6 +399,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     }
                 } else { // escaped: shader.wgsl:1222-1231
                     const V3 sky = sample_env_bilinear_finish(sky_fetch);
+                    if (kPackedMiss) sky_pmf = env_bilinear_pmf(P.env, sky_fetch, env_u, env_v);
                     const float pdf = sky_pmf / environment_pixel_solid_angle(env_v, P.env);
                     const float w = power_heuristic(last_pdf, pdf);
                     if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + nee_prev; // previous vertex, lit
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     surf = resolve_hit(S, h, o, d);
                     mat = load_material(S, surf.material_id);
                     SHADE_STAMP(11);
-                    es = sample_environment_finish(P.env, rng, pick);
+                    es = sample_environment_finish<RT_ENV_PACKED != 0>(P.env, rng, pick);
                     SHADE_STAMP(12);
                     // the previous vertex's NEE term, lit: :1246-1249 of the previous iteration
                     if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + nee_prev;

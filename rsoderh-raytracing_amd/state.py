@@ -24,7 +24,7 @@ _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "r
             "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_render",
             "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters", "rsrt_display_srgb8",
             "rsrt_selftest_numerics", "rsrt_build_id",
-            "rsrt_partition_owner", "rsrt_partition_mask", "rsrt_comm_unique_id", "rsrt_comm_init", "rsrt_comm_reduce", "rsrt_comm_destroy",
+            "rsrt_partition_owner", "rsrt_partition_mask", "rsrt_partition_tiles", "rsrt_comm_available", "rsrt_comm_unique_id", "rsrt_comm_init", "rsrt_comm_reduce", "rsrt_comm_destroy",
             "rsrt_multi_create", "rsrt_multi_destroy", "rsrt_multi_last_error", "rsrt_multi_size", "rsrt_multi_context",
             "rsrt_multi_upload_scene", "rsrt_multi_upload_environment", "rsrt_multi_resize", "rsrt_multi_clear", "rsrt_multi_render",
             "rsrt_multi_synchronize", "rsrt_multi_download", "rsrt_multi_display_srgb8", "rsrt_multi_get_stats", "rsrt_multi_uses_rccl"]
@@ -90,6 +90,9 @@ def lib():
         L.rsrt_partition_owner.restype = C.c_uint32
         L.rsrt_partition_owner.argtypes = [C.c_uint32] * 7
         L.rsrt_partition_mask.argtypes = [C.c_uint32] * 6 + [C.c_void_p, C.c_void_p]
+        L.rsrt_partition_tiles.argtypes = [C.c_uint32] * 6 + [C.c_void_p, C.c_void_p]
+        L.rsrt_comm_available.restype = C.c_int
+        L.rsrt_comm_available.argtypes = []
         L.rsrt_comm_unique_id.argtypes = [C.c_void_p]
         L.rsrt_comm_init.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.rsrt_comm_reduce.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -197,12 +200,17 @@ class State:
             raise RsrtError("rsrt_comm_unique_id failed (%d): %s" % (rc, L.rsrt_last_error(None).decode()))
         return buf.raw
 
+    @staticmethod
+    def comm_available():
+        """True when librccl can be loaded (a dlopen, no collective): every rank asks BEFORE the collective comm_init."""
+        return bool(lib().rsrt_comm_available())
+
     def comm_init(self, rank, world_size, unique_id):
         assert len(unique_id) == 128
         self._check(self._L.rsrt_comm_init(self._ctx, rank, world_size, C.create_string_buffer(unique_id, 128)), "rsrt_comm_init")
 
     def comm_reduce(self, root=0, recv_ptr=None, stream=None):
-        """One RCCL reduce(sum) of the accumulators onto `root` (in place unless recv_ptr names a device buffer)."""
+        """The exchange step: every rank's tiles onto `root` over RCCL (in place unless recv_ptr names a device buffer)."""
         self._check(self._L.rsrt_comm_reduce(self._ctx, root, C.c_void_p(recv_ptr) if recv_ptr else None,
                                              C.c_void_p(stream) if stream else None), "rsrt_comm_reduce")
 
@@ -306,7 +314,7 @@ class State:
 
 class MultiState:
     """`State` over a LIST of devices of one node, driven by one thread (rsrt_multi_*, include/rsrt.h): device i renders
-    tiles t % n == i, the frame is reduced onto devices[0] by RCCL inside the library when it is asked for."""
+    the tiles of rank i (partition.py), the frame is gathered onto devices[0] by RCCL inside the library when it is asked for."""
 
     def __init__(self, scene, environments, width, height, devices=(0,), camera=None):
         self._L = lib()

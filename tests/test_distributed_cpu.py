@@ -30,6 +30,73 @@ def _worker(rank, world, port, full_path, out_path):
     dist.destroy_process_group()
 
 
+def _gather_worker(rank, world, port, full_path, out_path):
+    sys.path.insert(0, util.ROOT)
+    from rsoderh_raytracing_amd import partition
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = np.load(full_path)
+    h, w = full.shape[:2]
+    mine = np.full_like(full, np.nan)  # what a rank does not own must never reach the frame
+    m = partition.owned_mask(w, h, rank, world)
+    mine[m] = full[m]
+    frame = partition.gather_tiles(mine, rank, world)
+    if rank == 0:
+        np.save(out_path, frame)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_compact_tile_gather_is_bit_exact(tmp_path, world):
+    """The product's exchange step (pack own tiles -> gather -> scatter on the root), rehearsed over gloo with the
+    library's own tile lists (rsrt_partition_tiles): 1 / world of the bytes of the dense reduce, the same frame."""
+    import oracle
+    import rsoderh_raytracing_amd as R
+    sc = R.Scene.load_toml(util.scene_path("house"))
+    img, _ = oracle.render(util.oracle_scene(sc), util.oracle_env(util.small_env()), sc.camera_uniform().view(oracle.CAMERA),
+                           72, 40, 0, 2, 4)
+    full_path, out_path = str(tmp_path / "full.npy"), str(tmp_path / "out.npy")
+    np.save(full_path, img)
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_gather_worker, args=(world, port, full_path, out_path), nprocs=world, join=True)
+    out = np.load(out_path)
+    assert np.array_equal(util.bits(out), util.bits(img))
+
+
+def test_tile_slots_of_the_library_match_the_formula_and_tile_the_frame():
+    from rsoderh_raytracing_amd import partition
+    for w, h, world, tw, th in [(1920, 1080, 8, 16, 16), (72, 40, 3, 16, 16), (17, 5, 2, 16, 16), (100, 60, 4, 32, 8), (200, 120, 6, 16, 16), (64, 64, 1, 16, 16)]:
+        tiles_x, tiles_y = partition.tile_grid(w, h, tw, th)
+        seen = np.zeros((tiles_y, tiles_x), np.int64)
+        lengths = set()
+        for r in range(world):
+            slots = partition.tile_slots(w, h, r, world, tw, th)
+            assert np.array_equal(slots, partition.tile_slots_numpy(w, h, r, world, tw, th))
+            lengths.add(len(slots))
+            for tx, ty in slots:
+                if tx >= 0:
+                    seen[ty, tx] += 1
+                    assert (tx + ty * partition.skew(world)) % world == r
+        assert len(lengths) == 1 and np.all(seen == 1)  # equal buffers for all ranks; every tile exactly once
+        # pack -> unpack is the identity on any image
+        img = np.arange(h * w * 4, dtype=np.float32).reshape(h, w, 4)
+        bufs = [partition.pack_tiles(np.where(partition.owned_mask(w, h, r, world, tw, th)[..., None], img, -1.0), r, world, tw, th) for r in range(world)]
+        assert np.array_equal(partition.unpack_tiles(bufs, w, h, tw, th), img)
+
+
+def test_a_ranks_tiles_are_a_lattice_not_column_stripes():
+    """1920 / 16 = 120 tiles per row = 0 mod 8: with t % world every rank would own fixed 16-pixel columns.  The skewed
+    ownership gives every rank tiles in every tile column (and every tile row) for 2, 4 and 8 ranks."""
+    from rsoderh_raytracing_amd import partition
+    for world in (2, 4, 8):
+        owner = partition.tile_owner_map(1920, 1080, world)[::16, ::16]
+        for r in range(world):
+            assert (owner == r).any(axis=0).all() and (owner == r).any(axis=1).all()
+        counts = np.bincount(owner.ravel(), minlength=world)
+        assert counts.max() - counts.min() <= owner.shape[0]  # within one tile per tile row
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_tile_partition_reduce_is_bit_exact(tmp_path, world):
     import oracle
@@ -52,7 +119,8 @@ def test_owner_map_covers_every_pixel_once():
         assert owner.min() >= 0 and owner.max() < world
         total = sum(partition.owned_mask(w, h, r, world).astype(np.int64) for r in range(world))
         assert np.all(total == 1)
-    # balance: tile counts per rank differ by at most one
+    # balance: every rank owns the same number of tile slots; real tiles per rank differ by at most one per tile row
     tx, ty = partition.tile_grid(1920, 1080)
-    counts = np.bincount(np.arange(tx * ty) % 8)
-    assert counts.max() - counts.min() <= 1
+    owner = partition.tile_owner_map(1920, 1080, 8)[::16, ::16]
+    counts = np.bincount(owner.ravel(), minlength=8)
+    assert counts.sum() == tx * ty and counts.max() - counts.min() <= ty
