@@ -16,8 +16,10 @@ metric = Mrays/s = (extension rays + issued shadow rays, counted on the device) 
 ms_per_step = ms/frame.
 
 roofline: the kernel's scene is LDS-resident and its environment MALL-resident, so HBM is not the
-roof it is under; FP32 VALU issue is.  `frac` = useful f32 lane-instructions per SIMD-cycle / 32 (a SIMD retires
-at most one wave64 VALU instruction per 2 cycles = 32 lanes per cycle), from rocprofv3 PMC counters collected
+roof it is under; FP32 VALU issue is.  `frac` = ALGORITHMIC lane-operations per second (the f32 / u32 operations the
+reference's integrator executes per path, counted by the oracle's counting build, x paths / launch time) / 78.64 T/s;
+`utilisation` = the kernel's own retired VALU lane-instructions per SIMD-cycle / 32 (a SIMD retires at most one
+wave64 VALU instruction per 2 cycles = 32 lanes per cycle), from rocprofv3 PMC counters collected
 LIVE by this run: before the GPU is touched, rank 0 (N = 1) starts `rocprofv3 --kernel-trace --pmc ... -- python3
 bench.py --pmc-child` four times (separate passes: SQ + GRBM, FETCH_SIZE + LDS, WRITE_SIZE + TCC hit / miss, read
 requests by size), each rendering one frame of the same workload with the same library.  If rocprofv3 cannot run, the committed counters of
@@ -120,8 +122,10 @@ def cpu_leg(scene, env, width, height, bounces, log):
     # counts for the algorithmic-byte model: the traversal the kernel executes — every node the reference visits for
     # extension rays, any-hit exit for shadow rays (pruning is not exactly result-preserving)
     t = time.time()
+    # ... through the counting build (liboracle_ops.so: same bits + the f32 / u32 operations the integrator executes)
     _, counts = oracle.render(osc, oenv, cam, width, height, 0, 1, bounces, flags=oracle.FLAG_ANYHIT_SHADOW,
-                              n_threads=cores, fast=True)
+                              n_threads=cores, fast="ops")
+    counts["leaf_boxes"] = int((np.asarray(scene.bvh_nodes["primitives_len"]) > 0).sum())
     t_counts = time.time() - t
     # timed baseline: the reference's own traversal, sized for roughly 15-20 s (calibrated on 2 spp)
     t = time.time()
@@ -236,8 +240,16 @@ def collect_pmc(args, log):
     return out
 
 
-def roofline_object(pmc, build_id, launch_ms, paths_per_launch, per_path, owned_pixels, spp):
-    """The roofline of the dominant kernel.  pmc: collect_pmc()'s result (or the committed one) or None."""
+def roofline_object(pmc, build_id, launch_ms, paths_per_launch, per_path, owned_pixels, spp, counts=None):
+    """The roofline of the dominant kernel.  pmc: collect_pmc()'s result (or the committed one) or None; counts: the
+    counting oracle's totals over sample 0 of every pixel (f32_ops, int_ops, paths, rays, nodes ...) or None.
+
+    frac        = ALGORITHMIC lane-operations per second / peak: (f32 + u32 operations per path, counted by the oracle's
+                  counting build on the reference's own walk) x paths per launch / launch time / (1,024 SIMDs x 32 lanes x
+                  2.4 GHz = 78.64 T/s).  What the reference's integrator needs, whatever the kernel executes for it.
+    utilisation = the kernel's own retired VALU lane-instructions per SIMD-cycle / 32 (counters): how busy the lanes are,
+                  scheduler, extra box tests and multi-instruction div / sqrt included.
+    overhead    = 1 - frac / utilisation: the share of the retired lane-instructions that is not algorithmic work."""
     algo = None
     if per_path is not None:
         algo_bytes = per_path * paths_per_launch + 16.0 * owned_pixels
@@ -247,18 +259,36 @@ def roofline_object(pmc, build_id, launch_ms, paths_per_launch, per_path, owned_
                           "(t-pruning changes 2 of 5.3e8 paths, DESIGN.md §2: the kernel tests what the reference tests) + any-hit shadow rays",
                 "note": "these bytes are served by LDS (scene) and L2 / Infinity Cache (environment): a fraction of the HBM peak above 1 "
                         "means HBM is not the roof"}
-    ro = {"bound": "valu", "achieved": None, "peak": LANES_PER_SIMD_CYCLE, "unit": "f32 lane-instructions per SIMD-cycle", "frac": None,
+    peak_tops = N_SIMD * LANES_PER_SIMD_CYCLE * MAX_CLOCK_HZ / 1e12
+    ro = {"bound": "valu", "achieved": None, "peak": peak_tops, "unit": "T lane-operations/s", "frac": None, "utilisation": None, "overhead": None,
           "traffic": None, "kernel": None, "build_id": build_id, "launch_ms": launch_ms, "sample_buffer_bytes_per_launch": 12.0 * paths_per_launch,
           "algorithmic": algo}
+    if counts is not None and counts.get("f32_ops"):
+        ops_per_path = (counts["f32_ops"] + counts["int_ops"]) / counts["paths"]
+        rays = counts["ext_rays"] + counts["shadow_rays"]
+        achieved = ops_per_path * paths_per_launch / (launch_ms * 1e-3) / 1e12
+        ro.update({"achieved": achieved, "frac": achieved / peak_tops,
+                   "work": {"f32_ops_per_path": counts["f32_ops"] / counts["paths"], "u32_ops_per_path": counts["int_ops"] / counts["paths"],
+                            "ops_per_launch": ops_per_path * paths_per_launch, "rays_per_path": rays / counts["paths"],
+                            "reference_walk_nodes_per_ray": counts["nodes_visited"] / rays, "primitive_tests_per_ray": counts["prim_refs"] / rays,
+                            "flat_loop_leaf_boxes_per_ray": counts.get("leaf_boxes"),
+                            "counted_by": "oracle/liboracle_ops.so (-DORC_COUNT_OPS) on sample 0 of every pixel: one per f32 add / sub / mul / div / fma / sqrt / "
+                                          "floor / min / max / comparison, detmath by polynomial path, u32 arithmetic and conversions apart; the reference's "
+                                          "own walk (every node it visits) for extension rays, first-hit exit for shadow rays",
+                            "note": "the flat loop tests every leaf box for every ray (flat_loop_leaf_boxes_per_ray) where the reference's walk visits "
+                                    "reference_walk_nodes_per_ray nodes: more box tests, bought for full lanes; that difference, the scheduler, and div / sqrt / "
+                                    "transcendentals costing several instructions each are what `overhead` holds"}})
     if pmc is None:
-        ro["note"] = "no PMC counters: rocprofv3 could not run here and no committed profile matches this library's build id"
+        ro["note"] = "no PMC counters: rocprofv3 could not run here and no committed profile matches this library's build id (frac needs none; utilisation does)"
         return ro
     c = pmc["counters"]
     cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs (guide: DVFS give-back)
     insts = c["SQ_INSTS_VALU"]
     lanes = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]  # lanes active per VALU instruction (both in quad-cycles)
     ipc = insts / (cycles * N_SIMD)
-    ro.update({"achieved": ipc * lanes, "frac": ipc * lanes / LANES_PER_SIMD_CYCLE, "kernel": pmc["kernel"],
+    util = ipc * lanes / LANES_PER_SIMD_CYCLE
+    ro.update({"utilisation": util, "overhead": (1.0 - ro["frac"] / util) if ro["frac"] is not None else None,
+               "utilisation_unit": "retired VALU lane-instructions per SIMD-cycle / 32", "kernel": pmc["kernel"],
                "counters": {k: c[k] for k in sorted(c)}, "counters_source": pmc["source"], "counters_build_id": pmc["build_id"],
                "launch_ms_under_pmc": pmc.get("launch_ms_under_pmc"),
                "valu": {"wave_instructions_per_launch": insts, "instructions_per_simd_cycle": ipc, "issue_peak_per_simd_cycle": 0.5,
@@ -303,7 +333,8 @@ def roofline_object(pmc, build_id, launch_ms, paths_per_launch, per_path, owned_
                      "bank_conflict_frac_of_busy": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], "wave_instructions_per_launch": c["SQ_INSTS_LDS"],
                      "note": "SQ_LDS_IDX_ACTIVE = LDS-array cycles summed over the 256 CUs; one array cycle moves up to 256 B"}
     ro["note"] = ("bound = FP32 VALU issue: the scene (10 KB) is read from LDS and the 64 MiB environment from L2 / Infinity Cache, so neither HBM "
-                  "nor MFMA is the roof this kernel is under; frac = (VALU wave-instructions per SIMD-cycle) x (lanes active per instruction) / 32")
+                  "nor MFMA is the roof this kernel is under; frac = algorithmic lane-operations (counted by the oracle) per second / 78.64 T/s; "
+                  "utilisation = (VALU wave-instructions per SIMD-cycle) x (lanes active per instruction) / 32, from live counters; frac <= utilisation <= 1")
     return ro
 
 
@@ -484,6 +515,8 @@ def main():
                 committed = json.load(f)
         if per_path is None and committed is not None:
             per_path = committed.get("algorithmic_bytes_per_path")
+        if counts is None and committed is not None and (committed.get("algorithmic_counts_1spp") or {}).get("f32_ops"):
+            counts = committed["algorithmic_counts_1spp"]  # (a property of the workload and of the reference's algorithm, not of the kernel)
         if pmc is not None and pmc["build_id"] != build_id:
             log("pmc: the child ran build %s, this process %s: counters dropped" % (pmc["build_id"], build_id))
             pmc = None
@@ -495,7 +528,8 @@ def main():
                 log("pmc: profiles/pmc_house_1080p_8b.json was taken on build %s, this library is %s: not attached" % (committed.get("build_id"), build_id))
         paths_per_launch = s["paths"] / launches_trace  # this rank's kernel
         owned_pixels = int(partition.owned_mask(W, H, rank, world).sum())
-        roofline = roofline_object(pmc if world == 1 else None, build_id, trace_ms_per_launch, paths_per_launch, per_path, owned_pixels, spp)
+        roofline = roofline_object(pmc if world == 1 else None, build_id, trace_ms_per_launch, paths_per_launch, per_path, owned_pixels, spp,
+                                   counts)
         if world > 1:
             roofline["note"] = "per-kernel counters are collected at N = 1 only; this object carries the launch time and the algorithmic bytes of rank 0's share"
         if args.write_profile and std_cfg and world == 1 and pmc is not None and str(pmc.get("source", "")).startswith("live"):

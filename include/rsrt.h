@@ -122,6 +122,18 @@ rsrt_status rsrt_upload_environment(rsrt_context *ctx, uint32_t slot, uint32_t w
 rsrt_status rsrt_environment_build_alias(rsrt_context *ctx, uint32_t slot, rsrt_alias_entry *host_out, size_t n_entries,
                                          uint32_t *leftover_out);
 
+/* build_bvh (src/bvh.rs:13-337) ON THE DEVICE (csrc/hip/rt_bvh_device.h): the arguments and outputs of the host
+ * builder rsrt_build_bvh (rsrt_host.h) — host arrays in, host arrays out: primitives_out holds n_spheres + n_planes + n_triangles
+ * entries, nodes_out room for twice that — and the same bits in both: level-parallel binned SAH with integer bucket counts,
+ * min / max bounds, the host's f32 cost expression, and the reference's unstable two-pointer partition reproduced as its
+ * closed-form permutation.  build_ms_out (may be NULL): device time of the build, uploads and downloads excluded.  A split that
+ * leaves one side empty (the reference's median fallback, unreachable for finite input) is RSRT_ERR_INVALID_ARGUMENT: use the
+ * host builder then. */
+rsrt_status rsrt_build_bvh_device(rsrt_context *ctx, const rsrt_sphere *spheres, uint32_t n_spheres, const rsrt_plane_desc *planes, uint32_t n_planes,
+                                  const rsrt_vec3 *vertices, uint32_t n_vertices, const rsrt_triangle *triangles, uint32_t n_triangles,
+                                  rsrt_primitive_info *primitives_out, rsrt_bvh_node *nodes_out, uint32_t *n_nodes_out, uint32_t *depth_out,
+                                  double *build_ms_out);
+
 /* -- multi-GPU framebuffer ownership (no reference counterpart) ---------------
  * The frame is cut into tile_w x tile_h pixel tiles; this context renders tile (tx, ty) iff (tx + ty * skew) % world_size ==
  * rank — interleaved in x, each tile row shifted by `skew` (the smallest odd number >= 3 coprime to world_size: 3 for 2, 4, 8
@@ -252,6 +264,18 @@ typedef struct rsrt_hit {
 } rsrt_hit;
 rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n_rays, const float *origins_xyz, const float *directions_xyz,
                            uint32_t mode, uint32_t flags, rsrt_hit *out);
+
+/* The wide walk's tree (csrc/hip/rt_device.h, trace_wide) for a BVH, built on the HOST exactly as rsrt_upload_scene builds it
+ * for the device (no GPU needed; tests/test_wide_tree.py walks it on the CPU): the binary tree collapsed into 4-wide nodes,
+ * breadth-first.  wnodes_out (may be NULL): 32 floats per wide node, 8 x {x, y, z, word} — slot k's exact box is {[2k].xyz,
+ * [2k + 1].xyz}; the words are the node's: [0] first interior child's node index (interior children come first and are consecutive)
+ * | interior-slot mask << 26, [1] first record of the node's leaf children, [2] / [3] which of the 32 records from there are
+ * triangles / planes, [4 + k] slot k's records as a mask from there (0: not a leaf); *n_wnodes: capacity in, count out; old_of_new (may be NULL):
+ * for every record index the walk uses (whole leaves are reordered so that a wide node's leaf records are contiguous), the
+ * index into `primitives` as given.  RSRT_ERR_INVALID_ARGUMENT: the BVH does not qualify (boxes that do not nest, leaves of
+ * more than 8 records or that share records, a tree too deep for the walk's register stack) and keeps the fixed-order walk. */
+rsrt_status rsrt_wide_tree_build(const rsrt_primitive_info *primitives, uint32_t n_primitives, const rsrt_bvh_node *bvh_nodes, uint32_t n_bvh_nodes,
+                                 float *wnodes_out, uint32_t *n_wnodes, uint32_t *old_of_new);
 
 /* Diagnostic words of an instrumented build (-DRT_INSTRUMENT: loop-trip counters behind
  * tools/simd_efficiency.py); all zero in the product build. Cumulative since context creation. */

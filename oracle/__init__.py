@@ -33,7 +33,7 @@ HIT = np.dtype([("did_hit", "u4"), ("distance", "f4"), ("hit_point", "f4", 3), (
 
 STAT_FIELDS = ["paths", "ext_rays", "shadow_rays", "nodes_visited", "prim_refs", "sphere_tests", "plane_tests",
                "tri_tests", "closest_tri", "nee_events", "escapes", "shaded_hits", "fallback_sphere_tests",
-               "fallback_plane_tests"]
+               "fallback_plane_tests", "f32_ops", "int_ops"]  # the last two: only fast="ops" (liboracle_ops.so) fills them
 FLAG_PRUNE = 1
 FLAG_ANYHIT_SHADOW = 2
 
@@ -76,8 +76,9 @@ _libs = {}
 
 def lib(fast=False):
     """fast: False = strict build (defines the golden values), True = -O3 twin (bit-identical), "libm" = the
-    sensitivity build (libm transcendentals, free contraction: NOT a parity reference)."""
-    name = "liboracle_libm.so" if fast == "libm" else ("liboracle_fast.so" if fast else "liboracle.so")
+    sensitivity build (libm transcendentals, free contraction: NOT a parity reference), "ops" = the counting build
+    (strict arithmetic + orc_stats.f32_ops / int_ops: the algorithmic work of the integrator)."""
+    name = {"libm": "liboracle_libm.so", "ops": "liboracle_ops.so"}.get(fast, "liboracle_fast.so" if fast else "liboracle.so")
     if name in _libs:
         return _libs[name]
     path = os.path.join(_HERE, name)

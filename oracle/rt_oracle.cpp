@@ -31,6 +31,13 @@
 #define rsrt_asinf asinf
 #endif
 
+#ifdef ORC_COUNT_OPS // the detmath routines, counted by what their polynomial path executes (see OPS below)
+static inline float orc_counted_sinf(float x);
+static inline float orc_counted_cosf(float x);
+static inline float orc_counted_atan2f(float y, float x);
+static inline float orc_counted_asinf(float x);
+#endif
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -45,41 +52,75 @@ namespace {
 
 typedef uint32_t u32;
 
+// -DORC_COUNT_OPS (liboracle_ops.so): the same restatement counting the f32 operations it executes — the ALGORITHMIC work of
+// the reference's integrator, the numerator of bench.py's roofline fraction.  Rules: one per f32 add, sub, mul, div, fma, sqrt,
+// floor, min, max and per f32 comparison; nothing for negation, abs, selects, moves and loads; the vector helpers count
+// themselves (dot = 3, cross = 6, normalize = 8 ...), every function below adds what its own scalar expressions execute
+// (the terms are written out next to the code), the detmath routines count the operations of their polynomial path
+// (include/rsrt_detmath.h; the two polynomial branches of sin / cos are averaged).  u32 arithmetic (the PCG draw, texel and
+// table indices) and u32 <-> f32 conversions are counted apart, as int_ops.  The counting build computes the same bits.
+#ifdef ORC_COUNT_OPS
+thread_local uint64_t g_f32_ops = 0, g_int_ops = 0; // (file scope through the unnamed namespace: the detmath wrappers below use them too)
+#define OPS(n) (g_f32_ops += (uint64_t)(n))
+#define IOPS(n) (g_int_ops += (uint64_t)(n))
+#else
+#define OPS(n) ((void)0)
+#define IOPS(n) ((void)0)
+#endif
+
+#ifdef ORC_COUNT_OPS
+} // namespace
+// sin / cos: 2 comparisons, x * 4/pi, 3 mul + 3 sub of the reduction, r * r, polynomial 7 (sin) or 9 (cos): 8 on average = 17;
+// atan2: 4 comparisons + y / x + w + atanf (3 comparisons, ~2 for the range reduction, z, 3 x (mul, add), mul mul add add) = 22;
+// asin: 4 comparisons, ~2 (0.5 (1 - a), sqrt | x * x), 4 x (mul, add), mul mul add, ~1 (r + r, pi/2 - r) = 18
+static inline float orc_counted_sinf(float x) { g_f32_ops += 17; g_int_ops += 6; return rsrt_sinf(x); }
+static inline float orc_counted_cosf(float x) { g_f32_ops += 17; g_int_ops += 6; return rsrt_cosf(x); }
+static inline float orc_counted_atan2f(float y, float x) { g_f32_ops += 22; return rsrt_atan2f(y, x); }
+static inline float orc_counted_asinf(float x) { g_f32_ops += 18; return rsrt_asinf(x); }
+#define rsrt_sinf orc_counted_sinf
+#define rsrt_cosf orc_counted_cosf
+#define rsrt_atan2f orc_counted_atan2f
+#define rsrt_asinf orc_counted_asinf
+namespace {
+#endif
+
 // ------------------------------------------------------------------ vector helpers
 struct V3 { float x, y, z; };
 inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 inline V3 v3(const float *p) { return V3{p[0], p[1], p[2]}; }
-inline V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
-inline V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
-inline V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
-inline V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
-inline V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
-inline V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+inline V3 operator+(V3 a, V3 b) { OPS(3); return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { OPS(3); return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, V3 b) { OPS(3); return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 operator*(V3 a, float s) { OPS(3); return V3{a.x * s, a.y * s, a.z * s}; }
+inline V3 operator*(float s, V3 a) { OPS(3); return V3{s * a.x, s * a.y, s * a.z}; }
+inline V3 operator/(V3 a, float s) { OPS(3); return V3{a.x / s, a.y / s, a.z / s}; }
 inline V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 inline float comp(V3 a, u32 i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
-inline float fmax_(float a, float b) { return a < b ? b : a; }
-inline float fmin_(float a, float b) { return b < a ? b : a; }
+inline float fmax_(float a, float b) { OPS(1); return a < b ? b : a; }
+inline float fmin_(float a, float b) { OPS(1); return b < a ? b : a; }
 inline float saturate(float x) { return fmin_(fmax_(x, 0.0f), 1.0f); }
 inline float fabs_(float x) { return fabsf(x); }
 
 // fused helpers (see header comment)
-inline float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
-inline float dot2(float ax, float ay, float bx, float by) { return fmaf(ay, by, ax * bx); }
+inline float dot(V3 a, V3 b) { OPS(3); return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+inline float dot2(float ax, float ay, float bx, float by) { OPS(2); return fmaf(ay, by, ax * bx); }
 inline V3 cross(V3 a, V3 b)
 {
+    OPS(6); // 3 mul + 3 fma
     return V3{fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y))};
 }
-inline V3 madd(V3 d, float t, V3 o) { return V3{fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z)}; }
+inline V3 madd(V3 d, float t, V3 o) { OPS(3); return V3{fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z)}; }
 struct M3 { V3 c0, c1, c2; };
 inline V3 mul(const M3 &m, V3 v)
 {
+    OPS(9); // 3 x (mul + 2 fma)
     return V3{fmaf(m.c2.x, v.z, fmaf(m.c1.x, v.y, m.c0.x * v.x)), fmaf(m.c2.y, v.z, fmaf(m.c1.y, v.y, m.c0.y * v.x)),
               fmaf(m.c2.z, v.z, fmaf(m.c1.z, v.y, m.c0.z * v.x))};
 }
-inline float length(V3 a) { return rsrt_sqrtf(dot(a, a)); }
-inline V3 normalize(V3 a) { return a * (1.0f / rsrt_sqrtf(dot(a, a))); }
-inline float inverse_sqrt(float x) { return 1.0f / rsrt_sqrtf(x); }
+inline float length(V3 a) { OPS(1); return rsrt_sqrtf(dot(a, a)); }
+inline V3 normalize(V3 a) { OPS(2); return a * (1.0f / rsrt_sqrtf(dot(a, a))); } // sqrt + div (+ dot 3 + scale 3)
+inline float inverse_sqrt(float x) { OPS(2); return 1.0f / rsrt_sqrtf(x); }
 
 inline u32 f2u(float x)
 {
@@ -121,12 +162,14 @@ inline u32 random_u32_uniform(u32 *s)
     *s = *s * 747796405u + 2891336453u; // :612
     u32 result = ((*s >> ((*s >> 28) + 4u)) ^ *s) * 277803737u; // :613-614
     result = (result >> 22) ^ result;   // :615
+    IOPS(9); // mul add | shr add shr xor mul | shr xor
     return result;
 }
-inline void salt_rng(u32 *s, u32 salt) { *s = *s ^ salt; random_u32_uniform(s); } // :605-609
-inline float random_uniform(u32 *s) { return (float)random_u32_uniform(s) / 4294967295.0f; } // :621-623
+inline void salt_rng(u32 *s, u32 salt) { IOPS(1); *s = *s ^ salt; random_u32_uniform(s); } // :605-609
+inline float random_uniform(u32 *s) { OPS(1); IOPS(1); return (float)random_u32_uniform(s) / 4294967295.0f; } // :621-623 (div; cvt)
 inline void random_in_circle_uniform(u32 *s, float *ox, float *oy) // :627-631
 {
+    OPS(2 + 1 + 2); // angle: 2 mul; sqrt; cx * r, cy * r
     float angle = random_uniform(s) * 2.0f * 3.1415926f;
     float cx = rsrt_cosf(angle), cy = rsrt_sinf(angle);
     float r = rsrt_sqrtf(random_uniform(s));
@@ -140,6 +183,7 @@ inline bool ray_intersects_bounds(const Ray &ray, const orc_bvh_node &n, V3 inv,
 {
     float t_0 = 0.0f, t_1 = INFINITY_;
     for (u32 axis = 0; axis < 3; axis++) {
+        OPS(2 + 2 + 4); // 2 sub, 2 mul, 4 comparisons (swap, t_0, t_1, t_0 > t_1)
         float t_near = (n.bmin[axis] - comp(ray.origin, axis)) * comp(inv, axis);
         float t_far = (n.bmax[axis] - comp(ray.origin, axis)) * comp(inv, axis);
         if (t_near > t_far) { float o = t_near; t_near = t_far; t_far = o; }
@@ -147,6 +191,7 @@ inline bool ray_intersects_bounds(const Ray &ray, const orc_bvh_node &n, V3 inv,
         if (t_far < t_1) t_1 = t_far;
         if (t_0 > t_1) return false;
     }
+    if (prune) OPS(1);
     if (prune && t_0 > best) return false;
     return true;
 }
@@ -161,12 +206,15 @@ inline HitInfo cast_ray_sphere(const Ray &ray, const orc_sphere &sp)
     float b = 2.0f * dot(ray.direction, l);
     float c = dot(l, l) - sp.radius * sp.radius;
     float t;
+    OPS(1 + 2 + 4 + 1); // b: mul; c: mul sub; discriminant: 3 mul + sub; < 0
     float discriminant = b * b - 4.0f * a * c;
     if (discriminant < 0.0f) {
         return NO_HIT;
     } else if (discriminant == 0.0f) {
+        OPS(1 + 2);
         t = -0.5f * b / a;
     } else {
+        OPS(1 + 1 + 3 + 2 + 2); // == 0; sqrt; b > 0, add / sub, mul; 2 div; 2 comparisons (+ fmin_)
         float sq = rsrt_sqrtf(discriminant);
         float q = (b > 0.0f) ? -0.5f * (b + sq) : -0.5f * (b - sq); // select(f, t, cond), :311-315
         float t_0 = q / a;
@@ -175,7 +223,9 @@ inline HitInfo cast_ray_sphere(const Ray &ray, const orc_sphere &sp)
         else if (t_1 < EPSILON) t = t_0;
         else t = fmin_(t_0, t_1);
     }
+    OPS(1);
     if (t < EPSILON) return NO_HIT;
+    OPS(2 + 1); // radius^2, sub; < 1e-6
     V3 hit_point = madd(ray.direction, t, ray.origin);
     V3 normal = normalize(hit_point - pos);
     V3 co = pos - ray.origin;
@@ -188,14 +238,18 @@ inline HitInfo cast_ray_plane(const Ray &ray, const orc_plane &pl)
 {
     V3 n = v3(pl.normal), pos = v3(pl.pos);
     float denominator = dot(n, ray.direction);
+    OPS(1);
     if (fabs_(denominator) < 0.0001f) return NO_HIT;
+    OPS(1 + 1); // div; t < 0.001
     float t = dot(n, pos - ray.origin) / denominator;
     if (t < 0.001f) return NO_HIT;
     V3 inter = madd(ray.direction, t, ray.origin);
     V3 inter_local = inter - pos;
     M3 m = {v3(pl.m[0]), v3(pl.m[1]), v3(pl.m[2])};
     V3 ps = mul(m, inter_local);
+    OPS(4);
     if (ps.x < 0.0f || 1.0f < ps.x || ps.z < 0.0f || 1.0f < ps.z) return NO_HIT;
+    OPS(1); // dot(origin, n) < 0
     V3 normal = n;
     if (dot(ray.origin, normal) < 0.0f) normal = normal * -1.0f; // :394 (origin NOT plane-relative)
     return HitInfo{true, t, inter, normal, pl.material_id};
@@ -211,14 +265,19 @@ inline HitInfo cast_ray_triangle(const Ray &ray, const orc_scene &sc, const orc_
     V3 perp_to_edge_0 = cross(op, edge_0);
     V3 perp_to_edge_1 = cross(ray.direction, edge_1);
     float determinant = dot(edge_0, perp_to_edge_1);
+    OPS(1 + 1); // div; |det| < 1e-8
     float inverse_determinant = 1.0f / determinant; // before the test, :421
     if (fabs_(determinant) < 1.0e-8f) return NO_HIT;
+    OPS(2 + 2); // u, v: a mul each; u < 0, 1 < u
     float u = dot(op, perp_to_edge_1) * inverse_determinant;
     float v = dot(ray.direction, perp_to_edge_0) * inverse_determinant;
     if (u < 0.0f || 1.0f < u) return NO_HIT;
+    if (u < 0.0f || 1.0f < u) {} else OPS(3); // v < 0, u + v, 1 < ..
     if (v < 0.0f || 1.0f < (u + v)) return NO_HIT;
+    OPS(1 + 1); // t: mul; t < 1e-5
     float t = dot(edge_1, perp_to_edge_0) * inverse_determinant;
     if (t < 1.0e-5f) return NO_HIT;
+    OPS(2 + 1); // 1 - u - v; dot(normal, dir) > 0
     V3 n0 = v3(sc.normals[tr.n0].v), n1 = v3(sc.normals[tr.n1].v), n2 = v3(sc.normals[tr.n2].v);
     V3 normal = normalize((1.0f - u - v) * n0 + u * n1 + v * n2);
     if (dot(normal, ray.direction) > 0.0f) normal = normal * -1.0f;
@@ -231,6 +290,7 @@ HitInfo cast_ray_bvh(const Ctx &cx, const Ray &ray, bool any_hit)
     const orc_scene &sc = *cx.sc;
     Stats &st = *cx.st;
     const bool prune = (cx.flags & ORC_FLAG_PRUNE) != 0;
+    OPS(3);
     V3 inv = v3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
     HitInfo result = {false, INFINITY_, {0, 0, 0}, {0, 0, 0}, 0u};
     u32 result_type = 0;
@@ -252,6 +312,7 @@ HitInfo cast_ray_bvh(const Ctx &cx, const Ray &ray, bool any_hit)
                     case 2: st.tri_tests++; h = cast_ray_triangle(ray, sc, sc.triangles[info.index]); break;
                     default: break;
                     }
+                    if (h.did_hit) OPS(1);
                     if (h.did_hit && h.distance < result.distance) {
                         result = h;
                         result_type = info.type;
@@ -262,6 +323,7 @@ HitInfo cast_ray_bvh(const Ctx &cx, const Ray &ray, bool any_hit)
                 stack_length--;
                 current = nodes_to_visit[stack_length];
             } else {
+                OPS(1);
                 if (comp(inv, node.axis) < 0.0f) { // :536
                     nodes_to_visit[stack_length++] = current + 1;
                     current = node.idx;
@@ -293,11 +355,13 @@ HitInfo cast_ray(const Ctx &cx, const Ray &ray)
     for (u32 i = 0; i < sc.n_spheres; i++) {
         cx.st->fallback_sphere_tests++;
         HitInfo h = cast_ray_sphere(ray, sc.spheres[i]);
+        if (h.did_hit) OPS(1);
         if (h.did_hit && h.distance < result.distance) result = h;
     }
     for (u32 i = 0; i < sc.n_planes; i++) {
         cx.st->fallback_plane_tests++;
         HitInfo h = cast_ray_plane(ray, sc.planes[i]);
+        if (h.did_hit) OPS(1);
         if (h.did_hit && h.distance < result.distance) result = h;
     }
     return result;
@@ -306,11 +370,13 @@ HitInfo cast_ray(const Ctx &cx, const Ray &ray)
 // ------------------------------------------------------------------ environment (shader.wgsl:667-831)
 inline void direction_to_equirectangular_uv(V3 d, float *u, float *v) // :710-714
 {
+    OPS(3 + 2);
     *u = rsrt_atan2f(d.z, d.x) * INV_PI * 0.5f + 0.5f;
     *v = 0.5f - rsrt_asinf(d.y) * INV_PI;
 }
 inline V3 equirectangular_uv_to_direction(float u, float v) // :718-732
 {
+    OPS(3 + 1 + 2); // phi; theta; sin_theta * cos(phi), * sin(phi)
     float phi = (2.0f * u - 1.0f) * PI;
     float theta = PI * v;
     float sin_theta = rsrt_sinf(theta), cos_theta = rsrt_cosf(theta);
@@ -318,6 +384,7 @@ inline V3 equirectangular_uv_to_direction(float u, float v) // :718-732
 }
 inline float environment_pixel_solid_angle(float v, const orc_env &e) // :739-749
 {
+    OPS(1 + 2 + 2); IOPS(2); // theta; 2 div; 2 mul; 2 cvt
     float theta = PI * v;
     float sin_t = fmax_(1.0e-6f, rsrt_sinf(theta));
     float d_phi = TWO_PI / (float)e.width;
@@ -333,6 +400,7 @@ inline u32 clamp_texel(float f, u32 n)
 // textureSampleLevel(.., uv, 0).xyz with the sampler of src/state.rs:134-142 (Appendix A3)
 inline V3 sample_env_bilinear(const orc_env &e, float u, float v)
 {
+    OPS(4 + 2 + 2 + 2 + 8 + 2); IOPS(2 + 4 + 8); // x, y; floor; fx, fy; xf + 1, yf + 1; clamp comparisons; gx, gy | cvt; texel cvt; addresses
     float x = u * (float)e.width - 0.5f, y = v * (float)e.height - 0.5f;
     float xf = floorf(x), yf = floorf(y);
     float fx = x - xf, fy = y - yf;
@@ -356,6 +424,7 @@ inline float environment_direction_pdf(const Ctx &cx, V3 dir) // :753-769
     const orc_env &e = *cx.env;
     float u, v;
     direction_to_equirectangular_uv(dir, &u, &v);
+    OPS(2 + 4 + 1); IOPS(4 + 4 + 2); // u * W, v * H; f2u's comparisons; pmf / ..
     u32 x = std::min(f2u(u * (float)e.width), e.width - 1);
     u32 y = std::min(f2u(v * (float)e.height), e.height - 1);
     u32 index = x + y * e.width;
@@ -366,6 +435,7 @@ inline u32 random_index_in_environment(const Ctx &cx, u32 *rng) // :689-706
 {
     const orc_env &e = *cx.env;
     u32 length = e.width * e.height;
+    OPS(1 + 2 + 1); IOPS(5); // u * N; f2u; u2 < probability
     u32 index = std::min(f2u(random_uniform(rng) * (float)length), length - 1);
     const orc_alias_entry &entry = e.alias[index];
     float u2 = random_uniform(rng); // select() evaluates all operands: always drawn
@@ -378,6 +448,7 @@ inline EnvironmentSample sample_environment(const Ctx &cx, u32 *rng) // :782-820
     u32 index = random_index_in_environment(cx, rng);
     u32 x = index % e.width, y = index / e.width;
     float jitter_x = random_uniform(rng), jitter_y = random_uniform(rng);
+    OPS(4 + 1); IOPS(2 + 4); // u, v: add + div each; pmf / ..
     float u = ((float)x + jitter_x) / (float)e.width;
     float v = ((float)y + jitter_y) / (float)e.height;
     EnvironmentSample s;
@@ -392,6 +463,7 @@ inline EnvironmentSample sample_environment(const Ctx &cx, u32 *rng) // :782-820
 struct Frame { V3 tangent, bitangent, normal; };
 inline Frame make_frame(V3 normal) // :55-67
 {
+    OPS(1);
     V3 helper = (fabs_(normal.z) < 0.999f) ? v3(0, 0, 1) : v3(1, 0, 0);
     V3 tangent = normalize(cross(helper, normal));
     V3 bitangent = cross(normal, tangent);
@@ -401,15 +473,16 @@ inline V3 to_frame_local(const Frame &f, V3 w) { return v3(dot(w, f.tangent), do
 inline V3 to_frame_world(const Frame &f, V3 l) { return normalize(f.tangent * l.x + f.bitangent * l.y + f.normal * l.z); }
 
 struct BsdfMaterial { V3 color; float metallic; float alpha; V3 f0; V3 emission; };
-inline V3 lerp_vec3f(V3 a, V3 b, float t) { return (1.0f - t) * a + t * b; } // :242
-inline float lerp_f32(float a, float b, float t) { return (1.0f - t) * a + t * b; }
+inline V3 lerp_vec3f(V3 a, V3 b, float t) { OPS(1); return (1.0f - t) * a + t * b; } // :242
+inline float lerp_f32(float a, float b, float t) { OPS(4); return (1.0f - t) * a + t * b; }
 inline float max_component(V3 v) { return fmax_(v.x, fmax_(v.y, v.z)); }
-inline float luminance(V3 c) { return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; } // :884
+inline float luminance(V3 c) { OPS(5); return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; } // :884
 inline BsdfMaterial make_bsdf_material(const orc_material &m) // :850-873
 {
     BsdfMaterial b;
     b.color = v3(m.color);
     b.metallic = m.metallic;
+    OPS(1);
     b.alpha = fmax_(0.001f, m.roughness * m.roughness);
     b.f0 = lerp_vec3f(v3(0.04f, 0.04f, 0.04f), v3(m.color), saturate(m.metallic));
     b.emission = v3(m.emission);
@@ -417,33 +490,38 @@ inline BsdfMaterial make_bsdf_material(const orc_material &m) // :850-873
 }
 inline V3 surface_kd(const BsdfMaterial &m) // :878-881
 {
+    OPS(2);
     V3 kd0 = m.color * (1.0f - saturate(m.metallic));
     return kd0 * (1.0f - max_component(m.f0));
 }
 inline V3 sample_cosine_hemisphere(float sx, float sy) // :892-901
 {
+    OPS(1 + 1 + 2 + 4 + 1); // sqrt; phi; x, y; 1 - x^2 - y^2; sqrt
     float r = rsrt_sqrtf(sx);
     float phi = TWO_PI * sy;
     float x = r * rsrt_cosf(phi), y = r * rsrt_sinf(phi);
     float z = rsrt_sqrtf(fmax_(0.0f, 1.0f - x * x - y * y));
     return v3(x, y, z);
 }
-inline float pdf_cosine_hemisphere(V3 wi) { return wi.z <= 0.0f ? 0.0f : wi.z / PI; } // :914-919
+inline float pdf_cosine_hemisphere(V3 wi) { OPS(2); return wi.z <= 0.0f ? 0.0f : wi.z / PI; } // :914-919
 inline float d_ggx(float ndh, float alpha) // :924-928
 {
+    OPS(1 + 4 + 3);
     float alpha_2 = alpha * alpha;
     float denominator = (ndh * ndh) * (alpha_2 - 1.0f) + 1.0f;
     return alpha_2 / (PI * denominator * denominator);
 }
 inline float lambda_ggx(float ndv, float alpha) // :1014-1020
 {
+    OPS(1 + 5 + 1 + 2); // ndv^2; 2 mul, sub, div, add; sqrt; - 1, / 2
     float ndv2 = ndv * ndv;
     return (rsrt_sqrtf(1.0f + alpha * alpha * (1.0f - ndv2) / ndv2) - 1.0f) / 2.0f;
 }
-inline float g1_ggx(float ndv, float alpha) { return 1.0f / (1.0f + lambda_ggx(ndv, alpha)); } // :1026
-inline float g_smith_ggx(float ndo, float ndi, float alpha) { return g1_ggx(ndo, alpha) * g1_ggx(ndi, alpha); }
+inline float g1_ggx(float ndv, float alpha) { OPS(2); return 1.0f / (1.0f + lambda_ggx(ndv, alpha)); } // :1026
+inline float g_smith_ggx(float ndo, float ndi, float alpha) { OPS(1); return g1_ggx(ndo, alpha) * g1_ggx(ndi, alpha); }
 inline V3 f_schlick(V3 f0, float cos_theta) // :1045-1051
 {
+    OPS(1 + 1 + 2);
     float x = 1.0f - saturate(cos_theta);
     float x_2 = x * x;
     float x_5 = x_2 * x_2 * x;
@@ -452,7 +530,9 @@ inline V3 f_schlick(V3 f0, float cos_theta) // :1045-1051
 inline float pdf_ggx_half_vector_visible(V3 h, V3 wo, float alpha) // :931-945
 {
     float ndh = h.z, ndo = wo.z;
+    OPS(1);
     if (ndh <= 0.0f) return 0.0f;
+    OPS(3);
     return d_ggx(ndh, alpha) * g1_ggx(ndo, alpha) * fmax_(0.0f, dot(wo, h)) / ndo;
 }
 inline V3 sample_ggx_visible_half_vector(float sx, float sy, V3 wo, float alpha) // :962-1009
@@ -460,6 +540,7 @@ inline V3 sample_ggx_visible_half_vector(float sx, float sy, V3 wo, float alpha)
     V3 vs = normalize(wo * v3(alpha, alpha, 1.0f));
     float length_squared = dot2(vs.x, vs.y, vs.x, vs.y);
     V3 alt = v3(-vs.y, vs.x, 0.0f) * inverse_sqrt(length_squared);
+    OPS(1 + 1 + 1 + 2 + 3 + 1 + 5 + 1 + 2); // > 0; sqrt; azimuth; dx, dy; 1 - dx^2, sqrt; 1 - dx^2 - dy^2, sqrt; alpha * hs.x, .y
     V3 tangent_x = (length_squared > 0.0f) ? alt : v3(1, 0, 0);
     V3 tangent_y = cross(vs, tangent_x);
     // sample_uniform_disk :907-911
@@ -472,7 +553,9 @@ inline V3 sample_ggx_visible_half_vector(float sx, float sy, V3 wo, float alpha)
 }
 inline V3 bsdf_eval_local(V3 wo, V3 wi, const BsdfMaterial &m) // :1053-1087
 {
+    OPS(2);
     if (wo.z <= 0.0f || wi.z <= 0.0f) return v3(0, 0, 0);
+    OPS(1 + 3); // D * G; / (4 ndo ndi)
     float ndo = wo.z, ndi = wi.z;
     V3 h = normalize(wo + wi);
     float ndh = saturate(h.z);
@@ -486,15 +569,20 @@ inline V3 bsdf_eval_local(V3 wo, V3 wi, const BsdfMaterial &m) // :1053-1087
 }
 inline float pdf_specular_wi_visible(V3 wo, V3 wi, float alpha) // :1089-1102
 {
+    OPS(2);
     if (wo.z <= 0.0f || wi.z <= 0.0f) return 0.0f;
     V3 h = normalize(wo + wi);
     float wo_dot_h = fabs_(dot(wo, h));
+    OPS(1);
     if (wo_dot_h <= 0.0f) return 0.0f;
+    OPS(2);
     return pdf_ggx_half_vector_visible(h, wo, alpha) / (4.0f * wo_dot_h);
 }
 inline float bsdf_pdf_local(V3 wo, V3 wi, const BsdfMaterial &m) // :1104-1114
 {
+    OPS(2);
     if (wo.z <= 0.0f || wi.z <= 0.0f) return 0.0f;
+    OPS(1 + 3);
     float ps = saturate(luminance(m.f0));
     float pd = 1.0f - ps;
     return pd * pdf_cosine_hemisphere(wi) + ps * pdf_specular_wi_visible(wo, wi, m.alpha);
@@ -503,19 +591,24 @@ struct BsdfSample { V3 ray_direction, scattering; float pdf; };
 inline BsdfSample bsdf_sample(const Ray &ray, V3 n, const BsdfMaterial &m, u32 *rng) // :1116-1202
 {
     V3 wo_world = -ray.direction;
+    OPS(1);
     if (dot(n, wo_world) <= 0.0f) return BsdfSample{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
     Frame frame = make_frame(n);
     V3 wo = to_frame_local(frame, wo_world);
+    OPS(1);
     if (wo.z <= 0.0f) return BsdfSample{v3(0, 0, 0), v3(0, 1, 0), 0.0f};
+    OPS(1 + 1); // pd; sample < pd
     float ps = saturate(luminance(m.f0));
     float pd = 1.0f - ps;
     V3 wi;
     float sample = random_uniform(rng);
     if (sample < pd) {
+        OPS(1);
         float s0 = sample / fmax_(pd, 1.e-6f);
         float s1 = random_uniform(rng);
         wi = sample_cosine_hemisphere(s0, s1);
     } else {
+        OPS(2 + 1 + 1); // s0; 2 * dot; wi.z <= 0
         float s0 = (sample - pd) / fmax_(ps, 1.e-6f);
         float s1 = random_uniform(rng);
         V3 h = sample_ggx_visible_half_vector(s0, s1, wo, m.alpha);
@@ -526,11 +619,13 @@ inline BsdfSample bsdf_sample(const Ray &ray, V3 n, const BsdfMaterial &m, u32 *
     V3 scattering = bsdf_eval_local(wo, wi, m);
     float pdf = bsdf_pdf_local(wo, wi, m);
     V3 wi_world = to_frame_world(frame, wi);
+    OPS(1);
     if (dot(n, wi_world) < 0.0f) return BsdfSample{v3(0, 0, 0), v3(0, 1, 0), 0.0f};
     return BsdfSample{wi_world, scattering, pdf};
 }
 inline float power_heuristic(float a, float b) // :1206-1210
 {
+    OPS(4);
     float a2 = a * a, b2 = b * b;
     return a2 / (a2 + b2);
 }
@@ -563,6 +658,7 @@ V3 trace_ray(const Ctx &cx, Ray ray, u32 *rng, u32 max_bounces)
             V3 wi_world = environment.direction;
             float cos_theta = fmax_(0.0f, dot(info.normal, wi_world));
             bool lit = false;
+            OPS(2);
             if (cos_theta > 0.0f && environment.pdf > 0.0f) {
                 st.shadow_rays++;
                 Ray shadow = {info.hit_point, environment.direction};
@@ -575,6 +671,7 @@ V3 trace_ray(const Ctx &cx, Ray ray, u32 *rng, u32 max_bounces)
                 V3 scattering = bsdf_eval_local(wo, wi, material);
                 float pdf_bsdf = bsdf_pdf_local(wo, wi, material);
                 float weight = power_heuristic(environment.pdf, pdf_bsdf);
+                OPS(0); // (the vector expression below counts itself: 3 mul-vec, 1 scale, 1 div-vec, 1 add)
                 incoming_light =
                     incoming_light + throughput * weight * environment.radiance * scattering * cos_theta / environment.pdf;
             }
@@ -585,7 +682,9 @@ V3 trace_ray(const Ctx &cx, Ray ray, u32 *rng, u32 max_bounces)
                 incoming_light = sample.scattering; // :1274 overwrites
                 break;
             }
+            OPS(3 + 1); // direction == 0 (x3); pdf <= 0
             if (sample.pdf <= 0.0f) break;
+            OPS(1 + 1); // cos / pdf; length < 0.001
             float cos_theta = fmax_(0.0f, dot(info.normal, sample.ray_direction));
             throughput = throughput * (sample.scattering * (cos_theta / sample.pdf));
             if (length(throughput) < 0.001f) break;
@@ -605,6 +704,7 @@ V3 pixel_sample(const Ctx &cx, const orc_camera &cam, u32 W, u32 H, u32 px, u32 
     salt_rng(&rng, sample_index);
     float jx, jy;
     random_in_circle_uniform(&rng, &jx, &jy);
+    OPS(2 + 4 + 4 + 1 + 1 + 3); IOPS(6); // fx, fy; sx; sy; fov / 2; aspect; ray_camera_space | cvt
     float fx = (float)px + jx, fy = (float)py + jy;
     float sx = ((fx / (float)W) * 2.0f - 1.0f) * 1.0f;
     float sy = ((fy / (float)H) * 2.0f - 1.0f) * -1.0f;
@@ -873,6 +973,9 @@ int orc_render(const orc_scene *scene, const orc_env *env, const orc_camera *cam
     {
         Stats local;
         Ctx cx = {scene, env, flags, &local};
+#ifdef ORC_COUNT_OPS
+        g_f32_ops = g_int_ops = 0;
+#endif
 #pragma omp for schedule(dynamic, 1)
         for (int tile = 0; tile < tiles_x * tiles_y; tile++) {
             u32 ty = (u32)(tile / tiles_x), tx = (u32)(tile % tiles_x);
@@ -886,6 +989,9 @@ int orc_render(const orc_scene *scene, const orc_env *env, const orc_camera *cam
                     }
                 }
         }
+#ifdef ORC_COUNT_OPS
+        local.f32_ops = g_f32_ops; local.int_ops = g_int_ops;
+#endif
 #pragma omp critical
         total.add(local);
     }

@@ -70,6 +70,8 @@ typedef struct {
     uint64_t nodes_visited, prim_refs, sphere_tests, plane_tests, tri_tests;
     uint64_t closest_tri, nee_events, escapes, shaded_hits;
     uint64_t fallback_sphere_tests, fallback_plane_tests;
+    uint64_t f32_ops, int_ops; /* liboracle_ops.so (-DORC_COUNT_OPS) only, else 0: the f32 operations (add, sub, mul, div, fma, sqrt,
+                                  floor, min, max, comparisons) and the u32 operations / conversions the integrator executed */
 } orc_stats;
 
 enum {

@@ -31,6 +31,9 @@
 #define RT_BLOCK 256
 #define RT_STATS_WORDS 40 // paths, ext, shadow, traversal steps + 32 diagnostic words (zero in the product build)
 #define RT_WAVE 64
+#ifndef RT_WALK_POOL
+#define RT_WALK_POOL 160u // path slots per wave of the 1024-thread walk kernels (hybrid scene view)
+#endif
 #ifndef RT_BIG_POOL
 #define RT_BIG_POOL 192u // RSRT_KERNEL=4: 1024-thread workgroups, this many slots per wave
 #endif
@@ -49,7 +52,7 @@ struct RenderParams {
     uint32_t samples_per_chunk, n_sblocks, n_chunks;
     uint32_t chunk_px, n_subtiles; // a chunk covers chunk_px consecutive pixels of a tile (tile_px / n_subtiles)
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
-    uint32_t trace_budget, descend_quorum, flat_quorum;
+    uint32_t trace_budget, descend_quorum, flat_quorum, stop_quorum;
     uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
     float *sample_buf;
     unsigned int *work_counter;
@@ -97,17 +100,18 @@ __device__ __forceinline__ SceneView<true> make_view<true>(const DevScene &sc)
     v.o_fbp = v.o_fbs + 4u * sc.n_spheres;
     v.o_flat = v.o_fbp + 4u * sc.n_planes;
     v.pnodes = sc.pnodes;
+    v.wnodes = sc.wnodes;
     return v;
 }
 template <>
 __device__ __forceinline__ SceneView<false> make_view<false>(const DevScene &sc)
 {
-    return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.escape, sc.flat_leaves, sc.pnodes};
+    return SceneView<false>{sc.nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.escape, sc.flat_leaves, sc.pnodes, sc.wnodes};
 }
 
 __device__ __forceinline__ SceneViewHybrid make_view_hybrid(const DevScene &sc)
 {
-    return SceneViewHybrid{0u, 2u * sc.n_nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.pnodes, sc.lds_float4s};
+    return SceneViewHybrid{0u, 2u * sc.n_nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.pnodes, sc.lds_float4s, sc.wnodes, sc.lds_hybrid};
 }
 
 // Copies the scene image into LDS (the arrays are contiguous in one device allocation, in the order
@@ -308,6 +312,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
 
 #include "rt_wavepool.h"
 #include "rt_alias_device.h"
+#include "rt_bvh_device.h"
 
 // total = textureLoad(cumulative) + sample, once per sample in order (shader.wgsl:1367-1371)
 __global__ __launch_bounds__(RT_BLOCK) void rt_resolve_kernel(RenderParams P, float4 *accum)
@@ -357,7 +362,9 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
 #endif
         uint32_t cur = 0, work = 0;
         unsigned long long flat_rem = 0ull;
-        while (cur != RT_END) trace_dispatch<(TRAV == 4 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, 50u, cur, h, nullptr, work, flat_rem);
+        uint32_t wmem[2 + RT_WSTACK]; // (the wide walk parks its stack here between calls, as the pool kernel does in the slot's cold columns)
+        constexpr int T = TRAV == 5 ? 4 : TRAV; // (probe numbering: 4 is the first kernel's stack walk, 5 the wide walk)
+        while (cur != RT_END) trace_dispatch<T>(DBG_ARG S, sc, o, d, prune, false, T == 4 ? 2u : 12u, 50u, cur, h, nullptr, work, flat_rem, wmem, 1u, 60u);
         // RSRT_PROBE_REPEAT (tools/trace_rate.py): the same query again and again, so that a timing of this kernel is a timing
         // of the traversal and not of staging the scene for 256 rays; the result does not change
         for (uint32_t k = 1; k < repeat; k++) {
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
             Hit h2;
             h2.t = RT_INFINITY; h2.ref = 0; h2.src = SRC_BVH; h2.u = h2.v = 0.0f;
             cur = 0;
-            while (cur != RT_END) trace_dispatch<(TRAV == 4 ? 0 : TRAV)>(DBG_ARG S, sc, o, d, prune, false, 12u, 50u, cur, h2, nullptr, work, flat_rem);
+            while (cur != RT_END) trace_dispatch<T>(DBG_ARG S, sc, o, d, prune, false, T == 4 ? 2u : 12u, 50u, cur, h2, nullptr, work, flat_rem, wmem, 1u, 60u);
             h.t = h2.t; h.ref = h2.ref; h.src = h2.src;
         }
         if (h.did_hit()) hit_barycentrics(S, h, o, d); // as SHADE does: the traversals do not carry u, v
@@ -445,6 +452,7 @@ static const void *pool_function(int trav)
     case 0: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 0>);
     case 1: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 1>);
     case 3: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 3>);
+    case 4: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 4>);
     default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 2>);
     }
 }
@@ -452,7 +460,7 @@ static const void *pool_function(int trav)
 static const void *variant_function(int kv, int sv, int trav)
 {
     if (kv == 0) return sv == 1 ? reinterpret_cast<const void *>(&rt_render_kernel<true>) : reinterpret_cast<const void *>(&rt_render_kernel<false>);
-    if (sv == 2) return pool_function<2, 1024, 160>(trav == 2 ? 1 : trav); // (the flat loop needs the whole image: never asked for here)
+    if (sv == 2) return pool_function<2, 1024, RT_WALK_POOL>(trav == 2 ? 1 : trav); // (the flat loop needs the whole image: never asked for here)
     if (kv == 1) return sv == 1 ? pool_function<1, RT_BLOCK, 192>(trav) : pool_function<0, RT_BLOCK, 192>(trav);
     if (kv == 3) return sv == 1 ? pool_function<1, RT_BLOCK, 128>(trav) : pool_function<0, RT_BLOCK, 128>(trav);
     if (kv == 4 && sv == 1) return pool_function<1, 1024, RT_BIG_POOL>(trav);
@@ -467,6 +475,7 @@ static const void *probe_function_sv(int trav)
     case 1: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 1>);
     case 2: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, (SV == 2 ? 1 : 2)>); // (flat needs the whole image: never asked for with SV 2)
     case 3: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 3>);
+    case 5: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 5>);
     default: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 4>);
     }
 }
@@ -486,7 +495,7 @@ struct rsrt_context {
     float4 *scene_blob = nullptr;
     DevScene scene{};
     bool scene_ready = false;
-    uint32_t hybrid_head_f4 = 0, hybrid_pnode_f4 = 0; // mid-size scenes: float4s of nodes + escape links / of the pre-order nodes (0 = too big for LDS)
+    uint32_t hybrid_head_f4 = 0, hybrid_pnode_f4 = 0, hybrid_wnode_f4 = 0; // mid-size scenes: float4s of nodes + escape links / of the pre-order nodes' / the wide nodes' top block (0 = none)
     // environments
     std::vector<Env> envs;
     // partition
@@ -496,11 +505,24 @@ struct rsrt_context {
     float4 *accum_owned = nullptr;
     uint32_t acc_w = 0, acc_h = 0;
     // work buffers
-    float *sample_buf = nullptr;
-    size_t sample_buf_bytes = 0;
-    uint32_t *cold_state = nullptr;
-    size_t cold_bytes = 0;
-    unsigned int *work_counter = nullptr;
+    // Two sets of work buffers ("lanes"), used in turn by successive passes: a pass's path-tracing kernel runs on its lane's own
+    // stream and touches nothing but its lane's buffers, so the kernel of call k + 1 fills the CUs that call k's tail is leaving
+    // (a launch ends with ~0.5 ms of pipeline drain: at one sample per call — the reference's interactive mode, src/state.rs:
+    // 760-833 — that was half the frame time).  Only the small resolve kernels, which add into the accumulator in sample
+    // order, stay chained on the caller's stream.  RSRT_OVERLAP=0: one lane, everything on the caller's stream (A/B).
+    struct Lane {
+        hipStream_t stream = nullptr;
+        unsigned int *work_counter = nullptr;
+        float *sample_buf = nullptr;
+        size_t sample_buf_bytes = 0;
+        uint32_t *cold_state = nullptr;
+        size_t cold_bytes = 0;
+        hipEvent_t resolved = nullptr; // recorded after the resolve that read this lane's sample buffer last
+        bool resolved_valid = false;
+    };
+    Lane lanes[2];
+    uint32_t next_lane = 0;
+    bool overlap = true;
     unsigned long long *dev_stats = nullptr;
     // stats
     rsrt_stats stats{};
@@ -529,13 +551,14 @@ struct rsrt_context {
     // scratch for rsrt_resolve_mean_f16 / rsrt_display_srgb8 (grow-only; no per-frame hipMalloc)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
-    int blocks_per_cu[12][RT_N_VARIANTS] = {}; // [scene view * 4 + traversal][kernel variant]
+    int blocks_per_cu[15][RT_N_VARIANTS] = {}; // [scene view * 5 + traversal][kernel variant]
     int kernel_variant = 4; // index into kVariantPool
-    int max_traversal = 3; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
+    int max_traversal = 4; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
     bool allow_flat = true;
     bool allow_hybrid = true;
     uint32_t trace_budget = 0; // traversal steps per TRACE invocation before a ray is re-queued (0: 6 for the fixed-order walk, 12 for the tree walks)
-    uint32_t descend_quorum = 30; // fixed-order walk: a descending round ends once fewer than this percentage of its lanes are still descending
+    uint32_t descend_quorum = 30; // fixed-order / wide walk: a descending round ends once fewer than this percentage of its lanes are still descending
+    uint32_t stop_quorum = 40; // wide walk: a TRACE call ends (the unfinished rays park their stacks) once fewer than this percentage of its lanes are still walking
     uint32_t chunks_per_wave = 32; // work chunks a resident wave should get at least (RSRT_CHUNKS_PER_WAVE): sets samples per chunk, and sub-tiles for small jobs
     uint32_t flat_quorum = 20; // flat traversal: the triangle loop ends once fewer than this percentage of its lanes still hold triangles (0: never)
     unsigned long long debug_words[32] = {0};
@@ -621,6 +644,107 @@ void make_material_record(const rsrt_material &m, float4 *r)
     r[3] = f4(kd[0], kd[1], kd[2], 1.0f - ps);
 }
 
+// ---- wide walk (rt_device.h, trace_wide): the binary tree collapsed into 4-wide nodes, breadth-first
+struct WideNode { uint32_t ch[4]; uint32_t n_ch, n_int, first_child; }; // binary nodes of the children (interior ones first), index of the first interior child's wide node
+// false: the scene does not qualify (see rsrt_upload_scene).  prims_out / nodes_out: `prims` with whole leaves reordered so that
+// the records of a wide node's leaf children are contiguous, and `nodes` with the leaves' first indices pointing there;
+// old_of_new (may be NULL): for every new record index the old one.
+bool build_wide_tree(const rsrt_bvh_node *nodes, uint32_t n_nodes, const rsrt_primitive_info *prims, uint32_t n_prims, std::vector<WideNode> &wide,
+                     std::vector<rsrt_primitive_info> &prims_out, std::vector<rsrt_bvh_node> &nodes_out, std::vector<uint32_t> *old_of_new)
+{
+    wide.clear();
+    bool ok = n_nodes >= 3 && nodes[0].primitives_len == 0;
+    {
+        std::vector<uint8_t> covered(n_prims, 0);
+        for (uint32_t i = 0; i < n_nodes && ok; i++) {
+            const rsrt_bvh_node &nd = nodes[i];
+            if (nd.primitives_len > 8) ok = false;
+            for (uint32_t k = 0; k < nd.primitives_len && ok; k++) {
+                uint8_t &c = covered[nd.primitives_or_second_child_index + k];
+                ok = c == 0;
+                c = 1;
+            }
+            if (nd.primitives_len == 0)
+                for (uint32_t c : {i + 1u, nd.primitives_or_second_child_index})
+                    for (int k = 0; k < 3; k++)
+                        ok = ok && nodes[c].bounds_min[k] >= nd.bounds_min[k] && nodes[c].bounds_max[k] <= nd.bounds_max[k];
+        }
+        for (uint32_t p = 0; p < n_prims; p++) ok = ok && covered[p]; // the permutation below must be total
+    }
+    if (!ok) return false;
+    auto area = [&](uint32_t i) {
+        const double dx = (double)nodes[i].bounds_max[0] - nodes[i].bounds_min[0], dy = (double)nodes[i].bounds_max[1] - nodes[i].bounds_min[1],
+                     dz = (double)nodes[i].bounds_max[2] - nodes[i].bounds_min[2];
+        const double a = dx * dy + dy * dz + dz * dx;
+        return a == a ? a : 0.0;
+    };
+    std::vector<uint32_t> queue{0u}, level{0u}; // binary roots of the wide nodes, breadth-first
+    uint32_t wdepth = 1;
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        const uint32_t r = queue[qi];
+        std::vector<uint32_t> ch{r + 1u, nodes[r].primitives_or_second_child_index};
+        while (ch.size() < 4) { // open the interior child with the largest box
+            int best = -1;
+            for (size_t k = 0; k < ch.size(); k++)
+                if (nodes[ch[k]].primitives_len == 0 && (best < 0 || area(ch[k]) > area(ch[best]))) best = (int)k;
+            if (best < 0) break;
+            const uint32_t c = ch[best];
+            ch[best] = c + 1u;
+            ch.insert(ch.begin() + best + 1, nodes[c].primitives_or_second_child_index);
+        }
+        WideNode w{};
+        for (uint32_t c : ch) if (nodes[c].primitives_len == 0) w.ch[w.n_ch++] = c; // interior children first ...
+        w.n_int = w.n_ch;
+        for (uint32_t c : ch) if (nodes[c].primitives_len != 0) w.ch[w.n_ch++] = c; // ... then the leaves
+        w.first_child = (uint32_t)queue.size(); // consecutive: breadth-first
+        for (uint32_t k = 0; k < w.n_int; k++) { queue.push_back(w.ch[k]); level.push_back(level[qi] + 1u); wdepth = std::max(wdepth, level[qi] + 2u); }
+        wide.push_back(w);
+    }
+    if (wdepth > RT_WSTACK + 1u || wide.size() >= (1u << 27)) { wide.clear(); return false; }
+    // whole leaves, in the order the wide nodes list them
+    prims_out.resize(n_prims);
+    nodes_out.assign(nodes, nodes + n_nodes);
+    if (old_of_new) old_of_new->resize(n_prims);
+    uint32_t at = 0;
+    for (const WideNode &w : wide)
+        for (uint32_t k = w.n_int; k < w.n_ch; k++) {
+            const rsrt_bvh_node &lf = nodes[w.ch[k]];
+            for (uint32_t j = 0; j < lf.primitives_len; j++) {
+                prims_out[at + j] = prims[lf.primitives_or_second_child_index + j];
+                if (old_of_new) (*old_of_new)[at + j] = lf.primitives_or_second_child_index + j;
+            }
+            nodes_out[w.ch[k]].primitives_or_second_child_index = at;
+            at += lf.primitives_len;
+        }
+    return true;
+}
+// the device records of the wide nodes (8 float4 each; rt_device.h, DevScene::wnodes) from the PERMUTED nodes / primitives
+void fill_wide_nodes(const std::vector<WideNode> &wide, const rsrt_bvh_node *nodes, const rsrt_primitive_info *prims, float4 *out)
+{
+    for (size_t wi = 0; wi < wide.size(); wi++) {
+        const WideNode &w = wide[wi];
+        float4 *q = out + 8 * wi;
+        uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // see DevScene::wnodes
+        words[0] = w.first_child | (((1u << w.n_int) - 1u) << 26);
+        if (w.n_ch > w.n_int) words[1] = nodes[w.ch[w.n_int]].primitives_or_second_child_index; // the leaves' records are contiguous from here
+        for (uint32_t k = 0; k < 4; k++) {
+            if (k >= w.n_ch) { q[2 * k] = q[2 * k + 1] = f4(0, 0, 0, 0); continue; } // (an empty slot's box may "hit": no mask names it)
+            const rsrt_bvh_node &nd = nodes[w.ch[k]]; // the child's EXACT box
+            q[2 * k] = f4(nd.bounds_min[0], nd.bounds_min[1], nd.bounds_min[2], 0);
+            q[2 * k + 1] = f4(nd.bounds_max[0], nd.bounds_max[1], nd.bounds_max[2], 0);
+            if (k < w.n_int) continue;
+            const uint32_t off = nd.primitives_or_second_child_index - words[1]; // < 32: four leaves of at most eight records
+            words[4 + k] = ((1u << nd.primitives_len) - 1u) << off;
+            for (uint32_t j = 0; j < nd.primitives_len; j++) {
+                const uint32_t ty = prims[nd.primitives_or_second_child_index + j].primitive_type;
+                if (ty >= 2) words[2] |= 1u << (off + j);
+                else if (ty == 1) words[3] |= 1u << (off + j);
+            }
+        }
+        for (int k = 0; k < 8; k++) q[k].w = u2f(words[k]);
+    }
+}
+
 rsrt_status ensure_accumulator(rsrt_context *ctx, uint32_t w, uint32_t h)
 {
     if (ctx->accum && ctx->acc_w == w && ctx->acc_h == h) return RSRT_OK;
@@ -655,6 +779,8 @@ rsrt_status end_work(rsrt_context *ctx, hipStream_t stream)
 rsrt_status sync_all(rsrt_context *ctx)
 {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &L : ctx->lanes)
+        if (L.stream) HIP_TRY(ctx, hipStreamSynchronize(L.stream));
     if (ctx->last_valid) HIP_TRY(ctx, hipEventSynchronize(ctx->last_event));
     return RSRT_OK;
 }
@@ -747,6 +873,7 @@ int select_traversal(const rsrt_context *ctx, const DevScene &sc, uint32_t max_b
     if (ctx->max_traversal >= 2 && ctx->allow_flat && sc.flat_ok && max_bounces <= RT_FLAT_MAX_BOUNCES) return 2;
     // RSRT_FLAG_PRUNE wants the reference's near-child-first order: a close hit found early is what lets later boxes be
     // skipped (the fixed-order walk prunes 4 % of suzanne's steps, the near-first walk 8 %)
+    if (ctx->max_traversal >= 4 && sc.wide_ok && !(flags & RSRT_FLAG_PRUNE)) return 4;
     if (ctx->max_traversal >= 3 && sc.typed_leaves && !(flags & RSRT_FLAG_PRUNE)) return 3;
     if (ctx->max_traversal >= 1 && sc.typed_leaves) return 1;
     return 0;
@@ -754,9 +881,12 @@ int select_traversal(const rsrt_context *ctx, const DevScene &sc, uint32_t max_b
 
 // One pass of rsrt_render: the path-tracing kernel over P.sample_count samples, then the ordered resolve.
 rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context::PassEvents &pe, const void *kfn, uint32_t block, int bpc,
-                         size_t smem, size_t per_sample, uint32_t max_bounces, hipStream_t stream)
+                         size_t smem, size_t per_sample, uint32_t max_bounces, hipStream_t caller_stream, rsrt_context::Lane &lane)
 {
     const uint32_t tile_px = P.tile_w * P.tile_h;
+    // the path-tracing kernel: on the lane's stream, after the resolve that last read this lane's sample buffer
+    const hipStream_t stream = ctx->overlap ? lane.stream : caller_stream;
+    if (ctx->overlap && lane.resolved_valid) HIP_TRY(ctx, hipStreamWaitEvent(stream, lane.resolved, 0));
     HIP_TRY(ctx, hipEventRecord(pe.begin, stream));
     if (max_bounces > 0) {
         // chunk = one tile x samples_per_chunk samples.  Up to 8 samples per chunk (2048 paths: the
@@ -782,7 +912,7 @@ rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context:
         const uint64_t n_chunks = (uint64_t)P.n_owned_tiles * P.n_sblocks * P.n_subtiles;
         if (n_chunks > 0xffffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "too many work chunks");
         P.n_chunks = (uint32_t)n_chunks;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, sizeof(unsigned int), stream));
+        HIP_TRY(ctx, hipMemsetAsync(lane.work_counter, 0, sizeof(unsigned int), stream));
         const uint32_t waves_wanted = (uint32_t)std::min<uint64_t>(n_chunks, 0x7fffffffull);
         const uint32_t wpb = block / RT_WAVE;
         uint32_t grid = std::min<uint32_t>((waves_wanted + wpb - 1) / wpb, (uint32_t)(ctx->cus * bpc));
@@ -791,13 +921,19 @@ rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context:
         HIP_TRY(ctx, hipLaunchKernel(kfn, dim3(grid), dim3(block), kargs, smem, stream));
         ctx->cum_launches++;
     } else {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->sample_buf, 0, per_sample * P.sample_count, stream));
+        HIP_TRY(ctx, hipMemsetAsync(lane.sample_buf, 0, per_sample * P.sample_count, stream));
     }
     HIP_TRY(ctx, hipEventRecord(pe.traced, stream));
-    hipLaunchKernelGGL(rt_resolve_kernel, dim3((P.n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, P, ctx->accum);
+    // the ordered resolve: on the caller's stream (where the accumulator's other users are), after this pass's kernel
+    if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(caller_stream, pe.traced, 0));
+    hipLaunchKernelGGL(rt_resolve_kernel, dim3((P.n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, caller_stream, P, ctx->accum);
     HIP_TRY(ctx, hipGetLastError());
     ctx->cum_launches++;
-    HIP_TRY(ctx, hipEventRecord(pe.end, stream));
+    HIP_TRY(ctx, hipEventRecord(pe.end, caller_stream));
+    if (ctx->overlap) {
+        HIP_TRY(ctx, hipEventRecord(lane.resolved, caller_stream));
+        lane.resolved_valid = true;
+    }
     return RSRT_OK;
 }
 
@@ -857,7 +993,12 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     DeviceGuard g(device_index);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->last_event, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipMalloc(&ctx->work_counter, sizeof(unsigned int))) != hipSuccess ||
+        (e = hipMalloc(&ctx->lanes[0].work_counter, sizeof(unsigned int))) != hipSuccess ||
+        (e = hipMalloc(&ctx->lanes[1].work_counter, sizeof(unsigned int))) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->lanes[0].stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->lanes[1].stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->lanes[0].resolved, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->lanes[1].resolved, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc(&ctx->dev_stats, RT_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(ctx->dev_stats, 0, RT_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess) {
         fail(nullptr, RSRT_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -865,19 +1006,21 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
         return RSRT_ERR_HIP;
     }
     for (int kv = 0; kv < RT_N_VARIANTS; kv++)
-        for (int m = 0; m < 12; m++) (void)hipFuncSetAttribute(variant_function(kv, m / 4, m % 4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int m = 0; m < 15; m++) (void)hipFuncSetAttribute(variant_function(kv, m / 5, m % 5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *kv = getenv("RSRT_KERNEL")) { // see kVariantPool
         int v = atoi(kv);
         if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
     }
+    if (const char *ov = getenv("RSRT_OVERLAP")) ctx->overlap = atoi(ov) != 0; // 0: one set of work buffers, every kernel on the caller's stream (A/B)
     if (const char *hy = getenv("RSRT_HYBRID")) ctx->allow_hybrid = atoi(hy) != 0; // 0: mid-size scenes read everything from global memory (A/B)
     if (const char *ty = getenv("RSRT_TRAVERSAL")) ctx->max_traversal = atoi(ty); // cap: 0 generic tree walk, 1 typed leaf loops, 2 + flat small-scene loop, 3 + fixed-order walk (A/B)
     if (const char *fl = getenv("RSRT_FLAT")) ctx->allow_flat = atoi(fl) != 0; // 0: small scenes take the walk a big scene would (A/B)
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
     if (const char *dq = getenv("RSRT_DESCEND_QUORUM")) { int v = atoi(dq); if (v >= 0 && v <= 100) ctx->descend_quorum = (uint32_t)v; }
+    if (const char *sq = getenv("RSRT_STOP_QUORUM")) { int v = atoi(sq); if (v >= 0 && v <= 100) ctx->stop_quorum = (uint32_t)v; }
     if (const char *cw = getenv("RSRT_CHUNKS_PER_WAVE")) { int v = atoi(cw); if (v >= 1 && v <= 4096) ctx->chunks_per_wave = (uint32_t)v; }
     if (const char *fq = getenv("RSRT_FLAT_QUORUM")) { int v = atoi(fq); if (v >= 0 && v <= 100) ctx->flat_quorum = (uint32_t)v; }
-    for (int m = 0; m < 15; m++) (void)hipFuncSetAttribute(probe_function(m / 5, m % 5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int m = 0; m < 18; m++) (void)hipFuncSetAttribute(probe_function(m / 6, m % 6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
     snprintf(buf, sizeof buf, "librsrt 0.1; %s (%s); %d CUs", prop.name, prop.gcnArchName, ctx->cus);
     ctx->description = buf;
@@ -900,9 +1043,13 @@ void rsrt_context_destroy(rsrt_context *ctx)
     (void)hipFree(ctx->scene_blob);
     for (auto &e : ctx->envs) { (void)hipFree(e.rgba); (void)hipFree(e.alias); }
     (void)hipFree(ctx->accum_owned);
-    (void)hipFree(ctx->sample_buf);
-    (void)hipFree(ctx->cold_state);
-    (void)hipFree(ctx->work_counter);
+    for (auto &L : ctx->lanes) {
+        (void)hipFree(L.sample_buf);
+        (void)hipFree(L.cold_state);
+        (void)hipFree(L.work_counter);
+        if (L.resolved) (void)hipEventDestroy(L.resolved);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
     (void)hipFree(ctx->dev_stats);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -920,11 +1067,13 @@ const char *rsrt_describe(rsrt_context *ctx) { return ctx ? ctx->description.c_s
 rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials, uint32_t n_materials, const rsrt_sphere *spheres,
                               uint32_t n_spheres, const rsrt_plane *planes, uint32_t n_planes, const rsrt_vec3 *vertices,
                               uint32_t n_vertices, const rsrt_vec3 *normals, uint32_t n_normals, const rsrt_triangle *triangles,
-                              uint32_t n_triangles, const rsrt_primitive_info *primitives, uint32_t n_primitives,
-                              const rsrt_bvh_node *nodes, uint32_t n_nodes)
+                              uint32_t n_triangles, const rsrt_primitive_info *primitives_in, uint32_t n_primitives,
+                              const rsrt_bvh_node *nodes_in, uint32_t n_nodes)
 {
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
     DeviceGuard g(ctx->device);
+    const rsrt_primitive_info *primitives = primitives_in; // (re-pointed below at a copy with whole leaves reordered, when the wide walk is built)
+    const rsrt_bvh_node *nodes = nodes_in;
     if (n_nodes == 0 || !nodes) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh_nodes is empty");
     if (n_nodes >= RT_END) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh_nodes: %u nodes exceed the 25-bit traversal cursor", n_nodes);
     if ((n_materials && !materials) || (n_spheres && !spheres) || (n_planes && !planes) || (n_vertices && !vertices) ||
@@ -975,6 +1124,20 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         }
         for (uint32_t i = 0; i < n_nodes; i++) // (the tables built below are indexed by every node)
             if (!seen[i]) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh node %u is not reachable from the root", i);
+    }
+    // ---- wide walk (rt_device.h, trace_wide): the binary tree collapsed into 4-wide nodes, breadth-first.  Needs what makes
+    // skipping binary nodes exact — every child box inside its parent's — plus leaves of <= 8 records that share none (the
+    // records of a wide node's leaf children are made contiguous by moving whole leaves: `primitives` and the leaves' first
+    // indices are re-pointed at permuted copies, and everything below is built from those; a record's index is internal to
+    // the device image, ties are decided by the visiting ranks computed from the tree) and a tree shallow enough for the
+    // walk's register stack.
+    std::vector<WideNode> wide;
+    std::vector<rsrt_primitive_info> prims_perm;
+    std::vector<rsrt_bvh_node> nodes_perm;
+    const bool wide_ok = build_wide_tree(nodes, n_nodes, primitives, n_primitives, wide, prims_perm, nodes_perm, nullptr);
+    if (wide_ok) {
+        primitives = prims_perm.data();
+        nodes = nodes_perm.data();
     }
     // ---- threaded traversal links: escape[octant][node] (rt_device.h, trace_threaded)
     std::vector<uint32_t> escape(8ull * n_nodes, RT_END);
@@ -1145,10 +1308,10 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     std::vector<uint32_t> new_id(n_nodes + 1, n_pnodes); // old node -> element; [n_nodes] = end
     for (uint32_t e = 0; e < n_pnodes; e++)
         if (plist[e].old != 0xffffffffu) new_id[plist[e].old] = e;
-    const size_t pnode_f4 = 2ull * n_pnodes, prank_f4 = (8ull * n_primitives + 3) / 4;
+    const size_t pnode_f4 = 2ull * n_pnodes, prank_f4 = (8ull * n_primitives + 3) / 4, wnode_f4 = 8ull * wide.size();
     // ---- build the device image: nodes | prims | escape links | tri normals | materials | fb spheres | fb planes
     const size_t n_f4 = 2ull * n_nodes + 4ull * n_primitives + 3ull * n_triangles + 4ull * n_materials + 4ull * n_spheres + 4ull * n_planes + esc_f4 + flat_f4;
-    std::vector<float4> img(n_f4 + rank_f4 + pnode_f4 + prank_f4); // what follows the LDS image: flat ranks | pre-order nodes | record ranks
+    std::vector<float4> img(n_f4 + rank_f4 + pnode_f4 + prank_f4 + wnode_f4); // what follows the LDS image: flat ranks | pre-order nodes | record ranks | wide nodes
     float4 *p = img.data();
     float4 *p_nodes = p;
     bool typed_leaves = true;
@@ -1231,6 +1394,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         }
     }
     if (n_primitives) memcpy(p_pnodes + pnode_f4, prim_rank.data(), prim_rank.size() * sizeof(uint32_t));
+    fill_wide_nodes(wide, nodes, primitives, p_pnodes + pnode_f4 + prank_f4);
 
     { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     if (ctx->scene_blob) { (void)hipFree(ctx->scene_blob); ctx->scene_blob = nullptr; }
@@ -1250,6 +1414,9 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.pnodes = ctx->scene_blob + n_f4 + rank_f4;
     sc.n_pnodes = n_pnodes;
     sc.prim_rank = reinterpret_cast<const uint32_t *>(ctx->scene_blob + n_f4 + rank_f4 + pnode_f4);
+    sc.wnodes = ctx->scene_blob + n_f4 + rank_f4 + pnode_f4 + prank_f4;
+    sc.n_wnodes = (uint32_t)wide.size();
+    sc.wide_ok = wide_ok ? 1u : 0u;
     sc.flat_ok = flat_ok ? 1u : 0u;
     sc.n_leaves = (uint32_t)leaf_nodes.size();
     sc.tri_mask_lo = (uint32_t)tri_mask; sc.tri_mask_hi = (uint32_t)(tri_mask >> 32);
@@ -1263,13 +1430,136 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.lds_float4s = (n_f4 * sizeof(float4) <= 24 * 1024) ? (uint32_t)n_f4 : 0u; // whole image in LDS only while it leaves room for the path pools
     sc.lds_hybrid = 0;
     sc.lds_src = sc.nodes; // the image starts with the nodes
-    ctx->hybrid_head_f4 = ctx->hybrid_pnode_f4 = 0;
+    ctx->hybrid_head_f4 = ctx->hybrid_pnode_f4 = ctx->hybrid_wnode_f4 = 0;
     if (sc.lds_float4s == 0) { // mid-size: what every box step touches goes to LDS, one big workgroup per CU shares the copy
         if (traversal_head_f4 * sizeof(float4) <= 40 * 1024) ctx->hybrid_head_f4 = (uint32_t)traversal_head_f4; // nodes + escape links (tree walks)
         ctx->hybrid_pnode_f4 = 2u * top_elems; // the top block of the fixed-order walk's nodes (all of them when the scene is mid-size)
+        ctx->hybrid_wnode_f4 = 8u * std::min<uint32_t>((uint32_t)wide.size(), kTopMax / 4u); // the wide walk's: breadth-first order puts the top of the tree first
     }
     memset(ctx->blocks_per_cu, 0, sizeof ctx->blocks_per_cu); // the kernels' dynamic LDS size depends on the scene: occupancy is asked for again
     ctx->scene_ready = true;
+    return RSRT_OK;
+}
+
+// build_bvh (reference src/bvh.rs:13-337) on the device: csrc/hip/rt_bvh_device.h.  Same arguments and outputs as the host
+// builder rsrt_build_bvh (include/rsrt_host.h) — host arrays in, host arrays out; the inputs are uploaded, the tree is built by
+// kernels, the result is downloaded — plus the time the device spent building (events around the kernels, uploads excluded).
+rsrt_status rsrt_build_bvh_device(rsrt_context *ctx, const rsrt_sphere *spheres, uint32_t n_spheres, const rsrt_plane_desc *planes, uint32_t n_planes,
+                                  const rsrt_vec3 *vertices, uint32_t n_vertices, const rsrt_triangle *triangles, uint32_t n_triangles,
+                                  rsrt_primitive_info *primitives_out, rsrt_bvh_node *nodes_out, uint32_t *n_nodes_out, uint32_t *depth_out, double *build_ms_out)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    const uint64_t n64 = (uint64_t)n_spheres + n_planes + n_triangles;
+    if (n64 == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "build_bvh: empty scene"); // (the reference asserts, src/bvh.rs:222)
+    if (n64 > 0x3fffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "build_bvh: too many primitives");
+    if (!primitives_out || !nodes_out || (n_spheres && !spheres) || (n_planes && !planes) || (n_triangles && (!triangles || !vertices)))
+        return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "build_bvh: NULL array");
+    for (uint32_t i = 0; i < n_triangles; i++)
+        if (triangles[i].vertex_0 >= n_vertices || triangles[i].vertex_1 >= n_vertices || triangles[i].vertex_2 >= n_vertices)
+            return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "build_bvh: triangle %u: vertex index out of range", i);
+    const uint32_t n = (uint32_t)n64;
+    { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
+    // one allocation: inputs | items x 2 (3 float4 arrays each) | build nodes | tasks x 2 | pre, holes, backs | counters | outputs
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_sph = take((size_t)n_spheres * sizeof(rsrt_sphere)), o_pl = take((size_t)n_planes * sizeof(rsrt_plane_desc)),
+                 o_v = take((size_t)n_vertices * sizeof(rsrt_vec3)), o_tri = take((size_t)n_triangles * sizeof(rsrt_triangle));
+    size_t o_items[6];
+    for (auto &o : o_items) o = take((size_t)n * sizeof(float4));
+    const size_t o_nodes = take((size_t)2 * n * sizeof(BvhNodeB)), o_t0 = take((size_t)n * sizeof(BvhTask)), o_t1 = take((size_t)n * sizeof(BvhTask));
+    const size_t o_pre = take((size_t)n * 4), o_holes = take((size_t)n * 4), o_backs = take((size_t)n * 4), o_cnt = take(16);
+    const size_t o_outn = take((size_t)2 * n * sizeof(rsrt_bvh_node)), o_outp = take((size_t)n * sizeof(rsrt_primitive_info));
+    char *blob = nullptr;
+    HIP_TRY(ctx, hipMalloc(&blob, off));
+    struct Free { char *p; ~Free() { (void)hipFree(p); } } free_blob{blob};
+    hipStream_t q = ctx->stream;
+    if (n_spheres) HIP_TRY(ctx, hipMemcpyAsync(blob + o_sph, spheres, (size_t)n_spheres * sizeof(rsrt_sphere), hipMemcpyHostToDevice, q));
+    if (n_planes) HIP_TRY(ctx, hipMemcpyAsync(blob + o_pl, planes, (size_t)n_planes * sizeof(rsrt_plane_desc), hipMemcpyHostToDevice, q));
+    if (n_vertices) HIP_TRY(ctx, hipMemcpyAsync(blob + o_v, vertices, (size_t)n_vertices * sizeof(rsrt_vec3), hipMemcpyHostToDevice, q));
+    if (n_triangles) HIP_TRY(ctx, hipMemcpyAsync(blob + o_tri, triangles, (size_t)n_triangles * sizeof(rsrt_triangle), hipMemcpyHostToDevice, q));
+    BvhItems A{reinterpret_cast<float4 *>(blob + o_items[0]), reinterpret_cast<float4 *>(blob + o_items[1]), reinterpret_cast<float4 *>(blob + o_items[2])};
+    BvhItems B{reinterpret_cast<float4 *>(blob + o_items[3]), reinterpret_cast<float4 *>(blob + o_items[4]), reinterpret_cast<float4 *>(blob + o_items[5])};
+    BvhNodeB *bnodes = reinterpret_cast<BvhNodeB *>(blob + o_nodes);
+    BvhTask *tasks[2] = {reinterpret_cast<BvhTask *>(blob + o_t0), reinterpret_cast<BvhTask *>(blob + o_t1)};
+    uint32_t *counters = reinterpret_cast<uint32_t *>(blob + o_cnt);
+    hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
+    struct Back { rsrt_context *c; hipEvent_t a, b; ~Back() { c->event_pool.push_back(a); c->event_pool.push_back(b); } } back{ctx, e0, e1};
+    HIP_TRY(ctx, hipEventRecord(e0, q));
+    hipLaunchKernelGGL(rt_bvh_items_kernel, dim3((n + 255) / 256), dim3(256), 0, q, reinterpret_cast<const rsrt_sphere *>(blob + o_sph), n_spheres,
+                       reinterpret_cast<const rsrt_plane_desc *>(blob + o_pl), n_planes, reinterpret_cast<const rsrt_vec3 *>(blob + o_v),
+                       reinterpret_cast<const rsrt_triangle *>(blob + o_tri), n_triangles, A);
+    HIP_TRY(ctx, hipMemcpyAsync(B.bmin, A.bmin, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, q)); // (a root that is a leaf never writes the other copy)
+    HIP_TRY(ctx, hipMemcpyAsync(B.bmax, A.bmax, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, q));
+    HIP_TRY(ctx, hipMemcpyAsync(B.cen, A.cen, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, q));
+    const BvhTask root{0u, n, 0u};
+    uint32_t cnt[4] = {1u, 0u, 0u, 0u}; // build nodes allocated, tasks of the next level, error
+    HIP_TRY(ctx, hipMemcpyAsync(tasks[0], &root, sizeof root, hipMemcpyHostToDevice, q));
+    HIP_TRY(ctx, hipMemcpyAsync(counters, cnt, sizeof cnt, hipMemcpyHostToDevice, q));
+    std::vector<std::pair<uint32_t, uint32_t>> levels; // first build node, count
+    uint32_t n_tasks = 1, first = 0, n_build = 1;
+    BvhItems *src = &A, *dst = &B;
+    for (int lvl = 0; n_tasks > 0; lvl++) {
+        if (lvl > 4096) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "build_bvh: tree deeper than 4096 levels");
+        levels.push_back({first, n_tasks});
+        hipLaunchKernelGGL(rt_bvh_level_kernel, dim3(n_tasks), dim3(RT_BVH_BLOCK), 0, q, tasks[lvl & 1], n_tasks, *src, *dst, bnodes, tasks[(lvl + 1) & 1], counters,
+                           reinterpret_cast<uint32_t *>(blob + o_pre), reinterpret_cast<uint32_t *>(blob + o_holes), reinterpret_cast<uint32_t *>(blob + o_backs));
+        hipLaunchKernelGGL(rt_bvh_copy_leaves_kernel, dim3(n_tasks), dim3(64), 0, q, tasks[lvl & 1], n_tasks, bnodes, *src, *dst);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(cnt, counters, sizeof cnt, hipMemcpyDeviceToHost, q));
+        HIP_TRY(ctx, hipStreamSynchronize(q));
+        if (cnt[2]) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "build_bvh: a split left one side empty (the reference's median fallback, src/bvh.rs:317-326, is not built on the device): use rsrt_build_bvh");
+        first = n_build;
+        n_tasks = cnt[1];
+        n_build = cnt[0];
+        cnt[1] = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(counters + 1, &cnt[1], 4, hipMemcpyHostToDevice, q));
+        std::swap(src, dst);
+    }
+    // (after the swap `src` names the copy the last level wrote: every range is final in it)
+    for (size_t d = levels.size(); d-- > 0;)
+        hipLaunchKernelGGL(rt_bvh_sizes_kernel, dim3((levels[d].second + 255) / 256), dim3(256), 0, q, bnodes, levels[d].first, levels[d].second);
+    for (size_t d = 0; d < levels.size(); d++)
+        hipLaunchKernelGGL(rt_bvh_positions_kernel, dim3((levels[d].second + 255) / 256), dim3(256), 0, q, bnodes, levels[d].first, levels[d].second);
+    hipLaunchKernelGGL(rt_bvh_emit_kernel, dim3((n_build + 255) / 256), dim3(256), 0, q, bnodes, n_build, reinterpret_cast<rsrt_bvh_node *>(blob + o_outn));
+    hipLaunchKernelGGL(rt_bvh_prims_kernel, dim3((n + 255) / 256), dim3(256), 0, q, *src, n, reinterpret_cast<rsrt_primitive_info *>(blob + o_outp));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(e1, q));
+    HIP_TRY(ctx, hipMemcpyAsync(nodes_out, blob + o_outn, (size_t)n_build * sizeof(rsrt_bvh_node), hipMemcpyDeviceToHost, q));
+    HIP_TRY(ctx, hipMemcpyAsync(primitives_out, blob + o_outp, (size_t)n * sizeof(rsrt_primitive_info), hipMemcpyDeviceToHost, q));
+    HIP_TRY(ctx, hipStreamSynchronize(q));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    if (n_nodes_out) *n_nodes_out = n_build;
+    if (depth_out) *depth_out = (uint32_t)levels.size() - 1u;
+    if (build_ms_out) *build_ms_out = ms;
+    return RSRT_OK;
+}
+
+// The wide walk's tree for a BVH, on the host (no GPU needed): what rsrt_upload_scene builds for the device, exposed so that a CPU
+// test can walk it.  wnodes_out: 32 floats per wide node (DevScene::wnodes); *n_wnodes: capacity in, count out; old_of_new: for
+// every record index the walk uses, the index into `primitives` as given.  RSRT_ERR_INVALID_ARGUMENT: the scene does not qualify.
+rsrt_status rsrt_wide_tree_build(const rsrt_primitive_info *primitives, uint32_t n_primitives, const rsrt_bvh_node *nodes, uint32_t n_nodes,
+                                 float *wnodes_out, uint32_t *n_wnodes, uint32_t *old_of_new)
+{
+    if (!primitives || !nodes || !n_wnodes || n_nodes == 0) return RSRT_ERR_INVALID_ARGUMENT;
+    for (uint32_t i = 0; i < n_nodes; i++) { // (the checks of rsrt_upload_scene that keep the builder's indexing in bounds)
+        const rsrt_bvh_node &nd = nodes[i];
+        if (nd.primitives_len > 0) { if ((uint64_t)nd.primitives_or_second_child_index + nd.primitives_len > n_primitives) return RSRT_ERR_INVALID_ARGUMENT; }
+        else if (i + 1 >= n_nodes || nd.primitives_or_second_child_index <= i + 1 || nd.primitives_or_second_child_index >= n_nodes) return RSRT_ERR_INVALID_ARGUMENT;
+    }
+    std::vector<WideNode> wide;
+    std::vector<rsrt_primitive_info> pp;
+    std::vector<rsrt_bvh_node> np;
+    std::vector<uint32_t> oon;
+    if (!build_wide_tree(nodes, n_nodes, primitives, n_primitives, wide, pp, np, &oon)) return RSRT_ERR_INVALID_ARGUMENT;
+    const uint32_t cap = *n_wnodes;
+    *n_wnodes = (uint32_t)wide.size();
+    if (wnodes_out) {
+        if (cap < wide.size()) return RSRT_ERR_INVALID_ARGUMENT;
+        fill_wide_nodes(wide, np.data(), pp.data(), reinterpret_cast<float4 *>(wnodes_out));
+    }
+    if (old_of_new) memcpy(old_of_new, oon.data(), oon.size() * sizeof(uint32_t));
     return RSRT_OK;
 }
 
@@ -1470,9 +1760,9 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const uint32_t tile_px = P.tile_w * P.tile_h;
     if ((uint64_t)P.n_owned_tiles * tile_px > 0x7fffffffull) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "frame too large");
     P.n_slots = P.n_owned_tiles * tile_px;
-    P.work_counter = ctx->work_counter;
     P.descend_quorum = ctx->descend_quorum;
     P.flat_quorum = ctx->flat_quorum;
+    P.stop_quorum = ctx->stop_quorum;
     P.stats = ctx->dev_stats;
     if (P.n_slots == 0) return RSRT_OK;
 
@@ -1483,33 +1773,26 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     uint32_t pass_samples = (uint32_t)std::max<size_t>(1, std::min<size_t>(sample_count, budget / per_sample));
     pass_samples = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(pass_samples, 0xffffffffull / P.n_slots)); // slot ids are 32-bit
     const size_t need = per_sample * pass_samples;
-    if (need > ctx->sample_buf_bytes) {
-        if ((st = sync_all(ctx))) return st;
-        if (ctx->sample_buf) { (void)hipFree(ctx->sample_buf); ctx->sample_buf = nullptr; ctx->sample_buf_bytes = 0; }
-        HIP_TRY(ctx, hipMalloc(&ctx->sample_buf, need));
-        ctx->sample_buf_bytes = need;
-    }
-    P.sample_buf = ctx->sample_buf;
 
     const int kv = ctx->kernel_variant;
     const int trav = select_traversal(ctx, P.scene, max_bounces, flags);
     int sv = P.scene.lds_float4s != 0 ? 1 : 0;
     if (sv == 0 && kv != 0 && ctx->allow_hybrid) { // mid-size scene: what the chosen traversal's box steps touch, in LDS (the first kernel has no hybrid form)
-        const uint32_t head = trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4;
-        if (head) { sv = 2; P.scene.lds_float4s = head; P.scene.lds_hybrid = 1; P.scene.lds_src = trav == 3 ? P.scene.pnodes : P.scene.nodes; }
+        const uint32_t head = trav == 4 ? ctx->hybrid_wnode_f4 : (trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4);
+        if (head) { sv = 2; P.scene.lds_float4s = head; P.scene.lds_hybrid = trav == 4 ? 3u : (trav == 3 ? 2u : 1u); P.scene.lds_src = trav == 4 ? P.scene.wnodes : (trav == 3 ? P.scene.pnodes : P.scene.nodes); }
     }
     // measured on suzanne and the 15 k-triangle grid (profiles/r02_bvh_knobs.txt): with the quorum vote a round is short, and
     // handing the slot back to the scheduler after about one round beats running several rounds with thinning lanes
-    P.trace_budget = ctx->trace_budget ? ctx->trace_budget : (trav == 3 ? 6u : 12u);
+    P.trace_budget = ctx->trace_budget ? ctx->trace_budget : (trav == 4 ? 4u : (trav == 3 ? 6u : 12u)); // (wide walk: rounds, not steps)
     const bool big = kv == 4 && sv == 1; // one workgroup per CU shares the scene copy
-    const uint32_t pool = (sv == 2 || (kv == 4 && !big)) ? 160u : kVariantPool[kv];
+    const uint32_t pool = sv == 2 ? RT_WALK_POOL : ((kv == 4 && !big) ? 160u : kVariantPool[kv]);
     const uint32_t block = (sv == 2 || big) ? 1024u : (uint32_t)RT_BLOCK;
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
                                 : scene_bytes + (size_t)(block / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
     const void *kfn = variant_function(kv, sv, trav);
-    int &bpc = ctx->blocks_per_cu[sv * 4 + trav][kv];
+    int &bpc = ctx->blocks_per_cu[sv * 5 + trav][kv];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, (int)block, smem);
@@ -1518,24 +1801,33 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         if (const char *o = getenv("RSRT_BLOCKS_PER_CU")) { int v = atoi(o); if (v > 0) bpc = std::min(bpc, v); } // experiment knob
     }
 
-    if (kv != 0) { // cold path-state arena: one block of columns per wave that can be resident
-        const size_t need_cold = (size_t)ctx->cus * bpc * (block / RT_WAVE) * pool_cold_columns(trav) * pool * sizeof(uint32_t);
-        if (need_cold > ctx->cold_bytes) {
-            if ((st = sync_all(ctx))) return st;
-            if (ctx->cold_state) { (void)hipFree(ctx->cold_state); ctx->cold_state = nullptr; ctx->cold_bytes = 0; }
-            HIP_TRY(ctx, hipMalloc(&ctx->cold_state, need_cold));
-            ctx->cold_bytes = need_cold;
-        }
-        P.cold_state = ctx->cold_state;
-    }
+    const size_t need_cold = kv != 0 ? (size_t)ctx->cus * bpc * (block / RT_WAVE) * pool_cold_columns(trav) * pool * sizeof(uint32_t) : 0; // cold path-state arena: one block of columns per wave that can be resident
     // the context's buffers are shared by every call: order this stream after whatever ran last (another stream's
     // render, rsrt_accumulator_clear on the context's own stream, ...)
     if ((st = begin_work(ctx, stream))) return st;
     for (uint32_t done = 0; done < sample_count; done += pass_samples) {
         P.sample_begin = sample_begin + done;
         P.sample_count = std::min(pass_samples, sample_count - done);
+        rsrt_context::Lane &lane = ctx->lanes[ctx->overlap ? ctx->next_lane : 0u];
+        if (ctx->overlap) ctx->next_lane ^= 1u;
+        if (need > lane.sample_buf_bytes || need_cold > lane.cold_bytes) { // (grow-only; a reallocation waits for everything in flight)
+            if ((st = sync_all(ctx))) { (void)end_work(ctx, stream); return st; }
+            if (need > lane.sample_buf_bytes) {
+                if (lane.sample_buf) { (void)hipFree(lane.sample_buf); lane.sample_buf = nullptr; lane.sample_buf_bytes = 0; }
+                HIP_TRY(ctx, hipMalloc(&lane.sample_buf, need));
+                lane.sample_buf_bytes = need;
+            }
+            if (need_cold > lane.cold_bytes) {
+                if (lane.cold_state) { (void)hipFree(lane.cold_state); lane.cold_state = nullptr; lane.cold_bytes = 0; }
+                HIP_TRY(ctx, hipMalloc(&lane.cold_state, need_cold));
+                lane.cold_bytes = need_cold;
+            }
+        }
+        P.sample_buf = lane.sample_buf;
+        P.cold_state = lane.cold_state;
+        P.work_counter = lane.work_counter;
         rsrt_context::PassEvents pe = {get_event(ctx), get_event(ctx), get_event(ctx)};
-        const rsrt_status pst = enqueue_pass(ctx, P, pe, kfn, block, bpc, smem, per_sample, max_bounces, stream);
+        const rsrt_status pst = enqueue_pass(ctx, P, pe, kfn, block, bpc, smem, per_sample, max_bounces, stream, lane);
         if (pst != RSRT_OK) { // nothing of this pass is pending: the three events go back to the pool
             ctx->event_pool.push_back(pe.begin); ctx->event_pool.push_back(pe.traced); ctx->event_pool.push_back(pe.end);
             (void)end_work(ctx, stream); // earlier passes may be in flight
@@ -1623,25 +1915,26 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
     DeviceGuard g(ctx->device);
     if (!ctx->scene_ready) return fail(ctx, RSRT_ERR_NOT_READY, "no scene uploaded");
     if (n == 0) return RSRT_OK;
-    if (!origins || !dirs || !out || mode > 31 || ((mode >> 1) & 7u) > 4u) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: bad arguments");
+    if (!origins || !dirs || !out || mode > 31 || ((mode >> 1) & 7u) > 5u) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: bad arguments");
     // mode: bit 0 = cast_ray_bvh only; bits 1-3 = traversal (0 threaded, 1 stack, 2 typed leaf loops, 3 flat, 4 fixed-order);
     // bit 4 = scene read from LDS exactly as the production kernel stages it for that traversal (whole image, or for a
     // mid-size scene the nodes + escape links / the pre-order nodes)
     DevScene sc = ctx->scene;
     const uint32_t sel = (mode >> 1) & 7u;
-    const int trav = sel == 0 ? 0 : (sel == 1 ? 4 : (sel == 2 ? 1 : (sel == 3 ? 2 : 3)));
+    const int trav = sel == 0 ? 0 : (sel == 1 ? 4 : (sel == 2 ? 1 : (sel == 3 ? 2 : (sel == 4 ? 3 : 5)))); // (probe numbering: 4 = stack walk, 5 = wide walk)
     int sv = 0;
     if (mode & 16u) {
         if (sc.lds_float4s != 0) {
             sv = 1;
         } else {
-            const uint32_t head = trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4;
+            const uint32_t head = trav == 5 ? ctx->hybrid_wnode_f4 : (trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4);
             if (head == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: this scene is not staged in LDS by the production kernel");
-            sv = 2; sc.lds_float4s = head; sc.lds_hybrid = 1; sc.lds_src = trav == 3 ? sc.pnodes : sc.nodes;
+            sv = 2; sc.lds_float4s = head; sc.lds_hybrid = trav == 5 ? 3u : (trav == 3 ? 2u : 1u); sc.lds_src = trav == 5 ? sc.wnodes : (trav == 3 ? sc.pnodes : sc.nodes);
         }
     } else {
         sc.lds_float4s = 0;
     }
+    if (trav == 5 && !sc.wide_ok) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: the wide walk needs nested boxes, leaves of at most 8 primitives that share no record, and a shallow enough tree");
     if ((trav == 1 || trav == 3) && !sc.typed_leaves) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: typed leaf loops need leaves of at most 8 primitives");
     if (trav == 2 && (!sc.flat_ok || sv == 2)) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: the flat traversal needs a scene of at most 64 records with nested boxes");
     { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }

@@ -61,7 +61,8 @@ struct DevScene {
     uint32_t n_nodes, n_prims, n_tris, n_materials, n_spheres, n_planes;
     uint32_t stack_entries;    // per-lane traversal stack entries (tree depth + 1)
     uint32_t lds_float4s;      // float4 count of the LDS image (0 = scene stays in global memory)
-    uint32_t lds_hybrid;       // the LDS image is only nodes | escape links (SceneViewHybrid, one 1024-thread workgroup per CU)
+    uint32_t lds_hybrid;       // the LDS image is only a traversal's head (SceneViewHybrid, one 1024-thread workgroup per CU): 1 nodes | escape
+                               // links (tree walks), 2 the top block of the fixed-order walk's nodes, 3 the top block of the wide walk's
     uint32_t typed_leaves;     // no leaf has more than 8 primitives: leaf node words carry triangle / plane masks (trace_threaded_typed)
     // flat small-scene traversal (trace_flat): at most 64 primitive records, every child box inside its parent's
     uint32_t flat_ok, n_leaves;
@@ -73,6 +74,12 @@ struct DevScene {
     const float4 *pnodes;
     uint32_t n_pnodes;
     const uint32_t *prim_rank;
+    // wide walk (trace_wide): 4-wide nodes collapsed from the binary tree, breadth-first (a node's interior children are
+    // consecutive), 8 float4 per node: slot k's EXACT box = {[2k].xyz, [2k + 1].xyz}; the .w words are the node's: [0] first
+    // interior child's node index | interior-slot mask << 26, [1] first record of the node's leaf children (contiguous), [2] / [3]
+    // which of the 32 records from there are triangles / planes, [4 + k] slot k's records as a mask from there (0: not a leaf)
+    const float4 *wnodes;
+    uint32_t n_wnodes, wide_ok;
     const float4 *lds_src; // what stage_scene_lds copies (lds_float4s float4s): the image, nodes | escape links, or the pre-order nodes
 };
 
@@ -96,7 +103,13 @@ template <>
 struct SceneView<true> {
     uint32_t o_nodes, o_prims, o_esc, o_trin, o_mats, o_fbs, o_fbp, o_flat;
     const float4 *pnodes; // (not part of the LDS image: small scenes run the flat loop, the pre-order walk is an A/B there)
+    const float4 *wnodes; // (likewise)
     RT_DEV void pnode_pair(uint32_t e, float4 &n0, float4 &n1) const { n0 = pnodes[2u * e]; n1 = pnodes[2u * e + 1u]; }
+    RT_DEV void wnode(uint32_t i, float4 (&n)[8]) const
+    {
+#pragma unroll
+        for (int k = 0; k < 8; k++) n[k] = wnodes[8u * i + k];
+    }
     RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
     RT_DEV float4 flat(uint32_t i) const { return rt_smem[o_flat + i]; }
     RT_DEV float4 prim(uint32_t i) const { return rt_smem[o_prims + i]; }
@@ -113,8 +126,13 @@ struct SceneView<true> {
 };
 template <>
 struct SceneView<false> {
-    const float4 *nodes, *prims, *tri_normals, *materials, *fb_spheres, *fb_planes, *escape, *flat_leaves, *pnodes;
+    const float4 *nodes, *prims, *tri_normals, *materials, *fb_spheres, *fb_planes, *escape, *flat_leaves, *pnodes, *wnodes;
     RT_DEV void pnode_pair(uint32_t e, float4 &n0, float4 &n1) const { n0 = pnodes[2u * e]; n1 = pnodes[2u * e + 1u]; }
+    RT_DEV void wnode(uint32_t i, float4 (&n)[8]) const
+    {
+#pragma unroll
+        for (int k = 0; k < 8; k++) n[k] = wnodes[8u * i + k];
+    }
     RT_DEV float4 node(uint32_t i) const { return nodes[i]; }
     RT_DEV float4 flat(uint32_t i) const { return flat_leaves[i]; }
     RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
@@ -135,14 +153,29 @@ struct SceneViewHybrid {
     const float4 *prims, *tri_normals, *materials, *fb_spheres, *fb_planes;
     const float4 *pnodes;
     uint32_t lds_f4;
-    // (the staged head is EITHER nodes | escape links OR the top block of the fixed-order walk's nodes)
+    const float4 *wnodes;
+    uint32_t head; // what the staged head holds (DevScene::lds_hybrid): the accessors of the other traversals read global memory
+    // Wide node i: from LDS when it is in the top block (the first lds_f4 / 8 nodes: breadth-first order puts the top of the
+    // tree there), else from global memory; same shape as pnode_pair below (unconditional ds_reads + global loads under a branch)
+    RT_DEV void wnode(uint32_t i, float4 (&n)[8]) const
+    {
+        const bool in_lds = (head == 3u) & (8u * i < lds_f4);
+        const uint32_t k0 = in_lds ? 8u * i : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) n[k] = rt_smem[k0 + k];
+        if (!in_lds) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) n[k] = wnodes[8u * i + k];
+        }
+    }
+    // (the staged head is EITHER nodes | escape links OR the top block of the fixed-order walk's nodes OR that of the wide walk's)
     // Element e of the fixed-order walk: from LDS when it is in the top block, else from global memory.  Written as an
     // unconditional ds_read (of element 0 for the lanes that are past the block) plus a global load under a branch:
     // a select between the two POINTERS makes the compiler emit flat loads, which take the texture path even for LDS
     // and are waited for one by one (measured: the walk ran 12 % slower than with three loads per step).
     RT_DEV void pnode_pair(uint32_t e, float4 &n0, float4 &n1) const
     {
-        const bool in_lds = 2u * e < lds_f4;
+        const bool in_lds = (head == 2u) & (2u * e < lds_f4); // (the wide walk's fallback for rays with a non-finite 1/d comes here with head == 3)
         const uint32_t k = in_lds ? 2u * e : 0u;
 #if RT_PNODE_GLOBAL_FIRST // A/B: global loads issued before the LDS reads, results selected (8 more v_cndmask, no LDS wait in front of the global loads)
         float4 g0 = float4{0, 0, 0, 0}, g1 = g0;
@@ -1421,18 +1454,237 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
     work += steps;
 }
 
+// ------------------------------------------------------------------ wide walk
+// The fixed-order walk above takes one dependent 32-byte fetch per box (38 a ray on the 15 k-triangle scene) and spends half
+// of its wave time waiting for them.  What the result depends on — the slab tests decide which leaves are tested, the ranks
+// decide equal t — leaves the SHAPE of the walk free, so the binary tree is collapsed at upload into 4-wide nodes (a node's
+// children are the binary node's children, the largest-area interior one replaced by its own two until there are four):
+// one fetch brings the EXACT boxes of four children, a quarter of the round trips for the same number of box tests
+// (tools/walk_sim.py).  Skipping the binary nodes in between is exact for the same reason the flat loop is: boxes nest and
+// f32 rounding is monotone, so with a finite 1/d a leaf's own box is hit only if every ancestor's is
+// (tests/test_box_containment.py); rays with a non-finite 1/d take the fixed-order walk, scenes whose boxes do not nest
+// never get here (rsrt_upload_scene, wide_ok).
+// Order: any (ties go by rank), so depth-first with the pending children of a level as ONE word — first child's node index
+// << 4 | 4-bit mask, a node's interior children being consecutive — and a stack of such words in registers (tree depth <=
+// RT_WSTACK + 1; deeper trees keep the fixed-order walk).  Leaves: the records of a node's leaf children are contiguous
+// (the upload permutes whole leaves), so what a lane holds for the primitive loops is one base index + three 32-bit masks.
+// A round = lanes visit nodes until they hold primitives (or a vote ends the wait) -> typed primitive loops.  A ray that is
+// not done when the wave stops (budget, or too few lanes left) parks its stack in the slot's cold columns (`wmem`).
+#define RT_WSTACK 8
+#define RT_WIDE_EMPTY 0xffffffffu
+struct WalkState {
+    uint32_t cur;  // node to visit next, RT_END: none
+    uint32_t grp;  // pending children of the current level: first child's index << 4 | mask
+    uint32_t s0, s1, s2, s3, s4, s5, s6, s7; // pending children of the levels above, s0 the innermost; 0 = none (a shift register: named
+                                             // scalars and whole-stack moves, because an indexed array would live in scratch memory)
+};
+static_assert(RT_WSTACK == 8, "WalkState names its eight stack words");
+RT_DEV void wstack_push(WalkState &w, uint32_t v)
+{
+    w.s7 = w.s6; w.s6 = w.s5; w.s5 = w.s4; w.s4 = w.s3; w.s3 = w.s2; w.s2 = w.s1; w.s1 = w.s0; w.s0 = v;
+}
+RT_DEV uint32_t wstack_pop(WalkState &w) // 0 when the stack is empty
+{
+    const uint32_t v = w.s0;
+    w.s0 = w.s1; w.s1 = w.s2; w.s2 = w.s3; w.s3 = w.s4; w.s4 = w.s5; w.s5 = w.s6; w.s6 = w.s7; w.s7 = 0u;
+    return v;
+}
+RT_DEV void wstate_load(WalkState &w, const uint32_t *m, uint32_t stride)
+{
+    w.cur = m[0]; w.grp = m[stride];
+    w.s0 = m[2u * stride]; w.s1 = m[3u * stride]; w.s2 = m[4u * stride]; w.s3 = m[5u * stride];
+    w.s4 = m[6u * stride]; w.s5 = m[7u * stride]; w.s6 = m[8u * stride]; w.s7 = m[9u * stride];
+}
+RT_DEV void wstate_store(const WalkState &w, uint32_t *m, uint32_t stride)
+{
+    m[0] = w.cur; m[stride] = w.grp;
+    m[2u * stride] = w.s0; m[3u * stride] = w.s1; m[4u * stride] = w.s2; m[5u * stride] = w.s3;
+    m[6u * stride] = w.s4; m[7u * stride] = w.s5; m[8u * stride] = w.s6; m[9u * stride] = w.s7;
+}
+
+#ifndef RT_WIDE_HOLD
+#define RT_WIDE_HOLD 6 // triangles a lane wants to hold before it stops visiting nodes (a shadow ray: any; its first hit ends it)
+#endif
+template <class View>
+RT_DEV void trace_wide(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V3 inv, bool anyhit, uint32_t budget, uint32_t quorum, uint32_t stop_quorum,
+                       WalkState &w, Hit &h, const uint32_t *ref_mem, uint32_t &work)
+{
+    const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    uint32_t steps = 0, rounds = 0;
+    const uint32_t started = (uint32_t)__popcll(__ballot(w.cur != RT_END));
+    // equal t: the record the reference meets first wins (rare: coincident geometry)
+#define RT_WIDE_ACCEPT(t, rec)                                                                                   \
+    bool better = ((t) >= 0.0f) & ((t) < h.t);                                                                      \
+    if (((t) == h.t) & (h.t < RT_INFINITY)) {                                                                       \
+        if (h.ref == RT_REF_UNKNOWN) h.ref = *ref_mem;                                                              \
+        better = prim_rank_of(sc, octant, (rec)) < prim_rank_of(sc, octant, h.ref);                                \
+    }                                                                                                               \
+    h.t = better ? (t) : h.t;                                                                                       \
+    h.ref = better ? (rec) : h.ref;
+    // What a lane holds for the triangle loop: a 64-record WINDOW of the (permuted) record array — the records of sibling nodes
+    // are neighbours there, so the leaves of several nodes usually share one window — plus, once a node's triangles fall outside
+    // it, that node's group as overflow; then the lane stops visiting and waits for the wave's triangle loop.
+    uint32_t win_base = 0u, ovf_base = 0u, ovf_tri = 0u;
+    unsigned long long tri_m = 0ull;
+    bool stopping = false;
+    for (;;) {
+        DBG_WAVE_TICK(14);
+        // ---- nodes, until this lane holds enough triangles; the wave stops waiting once fewer than `quorum` percent of the
+        // lanes that started the round are still looking
+        if (!stopping) {
+            const uint32_t want = anyhit ? 1u : (uint32_t)RT_WIDE_HOLD;
+            const uint32_t n_started = (uint32_t)__popcll(__ballot(true));
+            while (w.cur != RT_END && ovf_tri == 0u && (uint32_t)__popcll(tri_m) < want) {
+                DBG_WAVE_TICK(10);
+                DBG_ADD(11, 1);
+                steps++;
+                float4 n[8];
+                S.wnode(w.cur, n);
+                // the eight .w words are the node's, not the slots': [0] first interior child's node index | interior-slot mask << 26,
+                // [1] first record of the node's leaf children, [2] / [3] which of the 32 records from there are triangles / planes,
+                // [4 + k] the records of slot k (0 unless it is a leaf) — so a hit turns into masks with a select and an OR
+                uint32_t hm = 0u, lm = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float4 n0 = n[2 * k], n1 = n[2 * k + 1];
+                    const float ax = (n0.x - o.x) * inv.x, bx = (n1.x - o.x) * inv.x;
+                    const float ay = (n0.y - o.y) * inv.y, by = (n1.y - o.y) * inv.y;
+                    const float az = (n0.z - o.z) * inv.z, bz = (n1.z - o.z) * inv.z;
+                    const float t_0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz)), 0.0f);
+                    const float t_1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz)), RT_INFINITY);
+                    const bool hit = !(t_0 > t_1);
+                    hm |= hit ? (1u << k) : 0u;
+                    lm |= hit ? as_u(n[4 + k].w) : 0u;
+                }
+                const uint32_t wa = as_u(n[0].w);
+                const uint32_t im = hm & (wa >> 26); // (an empty slot is in neither mask: its "hit" goes nowhere)
+                const uint32_t rec_base = as_u(n[1].w), tri32 = as_u(n[2].w), pl32 = as_u(n[3].w);
+                steps += (uint32_t)__popc(lm);
+                bool stop = false;
+                // planes and spheres (rare inside a mesh's tree): tested here and now, one at a time
+                uint32_t oth = lm & ~tri32;
+                while (oth != 0u) {
+                    DBG_WAVE_TICK(15);
+                    DBG_ADD(13, 1);
+                    const uint32_t p = take_lowest(oth);
+                    const uint32_t rec = rec_base + p;
+                    const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u);
+                    float t;
+                    if ((pl32 >> p) & 1u) {
+                        const float4 r2 = S.prim(4u * rec + 2u), r3 = S.prim(4u * rec + 3u);
+                        t = plane_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), v3(r3.x, r3.y, r3.z));
+                    } else {
+                        t = sphere_t(o, d, v3(r0.x, r0.y, r0.z), r1.y);
+                    }
+                    RT_WIDE_ACCEPT(t, rec)
+                    if (better & anyhit) { stop = true; oth = 0u; }
+                }
+                // triangles: into the window if they fall inside it, else this node's group is the overflow
+                const uint32_t ltri = lm & tri32;
+                if (ltri != 0u) {
+                    const uint32_t shift = rec_base - win_base; // (wraps to a huge number when the group lies below the window)
+                    if (tri_m == 0ull) { win_base = rec_base; tri_m = ltri; }
+                    else if (shift <= 32u) tri_m |= (unsigned long long)ltri << shift;
+                    else { ovf_base = rec_base; ovf_tri = ltri; }
+                }
+                // where next: the hit interior children become the pending group of a new level (the old one goes on the stack)
+                if (im != 0u) {
+                    if ((w.grp & 15u) != 0u) wstack_push(w, w.grp);
+                    w.grp = ((wa & 0x3ffffffu) << 4) | im; // interior children are consecutive: slot k is node (first child) + k
+                } else if ((w.grp & 15u) == 0u) {
+                    w.grp = wstack_pop(w);
+                }
+                if ((w.grp & 15u) != 0u) {
+                    w.cur = (w.grp >> 4) + (uint32_t)__builtin_ctz(w.grp);
+                    w.grp &= w.grp - 1u;
+                } else {
+                    w.cur = RT_END;
+                }
+                if (stop) { w.cur = RT_END; tri_m = 0ull; ovf_tri = 0u; }
+                if ((uint32_t)__popcll(__ballot((w.cur != RT_END) & (ovf_tri == 0u) & ((uint32_t)__popcll(tri_m) < want))) * 100u < n_started * quorum) break; // wave-uniform
+            }
+        }
+        // ---- the triangles of the window, two records in flight per trip.  Lanes hold very different numbers of them, so the wave
+        // votes here too: once fewer than `quorum` percent of the lanes that entered still hold triangles the loop ends, and what a
+        // lane has left simply stays in its window for the next round (nothing to save, nothing tested twice) — unless the wave
+        // is about to stop, when everything held is tested
+        const uint32_t tri_started = (uint32_t)__popcll(__ballot(tri_m != 0ull));
+        while (tri_m != 0ull) {
+            DBG_WAVE_TICK(12);
+            DBG_ADD(13, 1);
+            const uint32_t rec_a = win_base + (uint32_t)__builtin_ctzll(tri_m);
+            tri_m &= tri_m - 1ull;
+            const bool two = tri_m != 0ull;
+            const uint32_t rec_b = two ? win_base + (uint32_t)__builtin_ctzll(tri_m) : rec_a;
+            tri_m &= tri_m - 1ull; // (0 & anything = 0)
+            const float4 a0 = S.prim(4u * rec_a), a1 = S.prim(4u * rec_a + 1u), a2 = S.prim(4u * rec_a + 2u);
+            const float4 b0 = S.prim(4u * rec_b), b1 = S.prim(4u * rec_b + 1u), b2 = S.prim(4u * rec_b + 2u);
+            float u, v;
+            bool stop = false;
+            {
+                const float t = triangle_t(o, d, v3(a0.x, a0.y, a0.z), v3(a1.x, a1.y, a1.z), v3(a2.x, a2.y, a2.z), u, v);
+                RT_WIDE_ACCEPT(t, rec_a)
+                stop = better & anyhit;
+            }
+            if (two & !stop) {
+                DBG_ADD(13, 1);
+                const float t = triangle_t(o, d, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z), v3(b2.x, b2.y, b2.z), u, v);
+                RT_WIDE_ACCEPT(t, rec_b)
+                stop = better & anyhit;
+            }
+            if (stop) { w.cur = RT_END; tri_m = 0ull; ovf_tri = 0u; }
+            if (!stopping && (uint32_t)__popcll(__ballot(tri_m != 0ull)) * 100u < tri_started * quorum) break; // wave-uniform
+        }
+        if (ovf_tri != 0u && tri_m == 0ull) { win_base = ovf_base; tri_m = ovf_tri; ovf_tri = 0u; } // the overflow group opens the next window
+        // ---- go on?  A lane leaves when it is done, or when the wave stops and it holds nothing (what it holds is tested first)
+        if (stopping) {
+            if (tri_m == 0ull) break;
+            continue;
+        }
+        rounds++; // (wave-uniform: every lane still here has run the same number of rounds)
+        stopping = rounds >= budget || (uint32_t)__popcll(__ballot((w.cur != RT_END) | (tri_m != 0ull))) * 100u < started * stop_quorum;
+        if (tri_m == 0ull && (stopping || w.cur == RT_END)) break;
+    }
+#undef RT_WIDE_ACCEPT
+    work += steps;
+}
+
 // ------------------------------------------------------------------ which traversal runs
 // TRAV: 0 trace_threaded (any BVH), 1 trace_threaded_typed (no leaf longer than 8 primitives), 2 trace_flat (<= 64
-// records, nested boxes), 3 trace_preorder (no leaf longer than 8 primitives).  One function so that the production
+// records, nested boxes), 3 trace_preorder (no leaf longer than 8 primitives), 4 trace_wide (nested boxes, leaves that
+// share no record, <= 8 primitives a leaf, wide tree no deeper than RT_WSTACK + 1).  One function so that the production
 // kernel's TRACE stage and the ray-query probe (rsrt_cast_rays) run the very same code.  `cur` is the traversal cursor
 // (0 = start at the root, RT_END = done), `h` the best hit so far; the tree walks stop after ~`budget` steps and are
 // resumed by calling again.  `ref_mem`: see trace_preorder.  `work` += box steps + primitive tests of the tree walks
 // (the flat loop, whose work per ray is fixed by the scene, adds nothing).
+// TRAV 4 (trace_wide): `cur` is 0 for a fresh ray, RT_END when done, and otherwise says that the walk's stack waits in `wmem`
+// (this slot's cold columns, `wstride` dwords apart: next node, pending group, RT_WSTACK stack words) — 1.
+// Rays with a non-finite 1/d take the fixed-order walk, for which `cur` is that walk's cursor; which of the two a ray takes
+// is a function of the ray alone, so a resumed ray reads its `cur` the way it was written.
 template <int TRAV, class View>
 RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t quorum, uint32_t &cur,
-                           Hit &h, const uint32_t *ref_mem, uint32_t &work, unsigned long long &flat_rem)
+                           Hit &h, const uint32_t *ref_mem, uint32_t &work, unsigned long long &flat_rem, uint32_t *wmem = nullptr, uint32_t wstride = 0,
+                           uint32_t stop_quorum = 0)
 {
-    if (TRAV == 2) {
+    if (TRAV == 4) {
+        const V3 inv = rt_rcp3(d);
+        const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f; // (as for the flat loop below)
+        if (finite == 0.0f) {
+            WalkState w;
+            w.cur = 0u; w.grp = 0u;
+            w.s0 = w.s1 = w.s2 = w.s3 = w.s4 = w.s5 = w.s6 = w.s7 = 0u;
+            if (cur != 0u) wstate_load(w, wmem, wstride); // parked by an earlier call
+            trace_wide(DBG_ARG S, sc, o, d, inv, anyhit, budget, quorum, stop_quorum, w, h, ref_mem, work);
+            if (w.cur == RT_END) {
+                cur = RT_END;
+            } else {
+                wstate_store(w, wmem, wstride);
+                cur = 1u;
+            }
+        } else {
+            trace_preorder(DBG_ARG S, sc, o, d, prune, anyhit, 0xffffffffu, 0u, cur, h, ref_mem, work);
+        }
+    } else if (TRAV == 2) {
         const V3 inv = rt_rcp3(d);
         // 0 * x is NaN exactly when x is infinite or NaN (an overflowing sum only sends a ray the long way round)
         const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f;

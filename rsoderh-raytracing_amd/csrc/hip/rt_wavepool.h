@@ -76,7 +76,13 @@ enum ColdField {
 #define RT_FLAT_BOUNCE_BITS 0xffff00u
 #define RT_FLAT_RESUMED (1u << 24)
 #define RT_FLAT_MAX_BOUNCES 0xffffu // 16 bits of the 25; rsrt_render picks a tree-walk kernel beyond that
-__host__ __device__ constexpr uint32_t pool_cold_columns(int trav) { return (RT_COLD_COMPACT && trav == 2) ? (uint32_t)C_COUNT_FLAT : (uint32_t)C_COUNT; }
+// the wide walk parks an unfinished ray's stack in columns of its own (next node, pending group, RT_WSTACK stack words); only such rays touch them
+#define C_WIDE_STATE ((uint32_t)C_COUNT)
+#define C_COUNT_WIDE ((uint32_t)C_COUNT + 2u + RT_WSTACK)
+__host__ __device__ constexpr uint32_t pool_cold_columns(int trav)
+{
+    return (RT_COLD_COMPACT && trav == 2) ? (uint32_t)C_COUNT_FLAT : (trav == 4 ? C_COUNT_WIDE : (uint32_t)C_COUNT);
+}
 enum PoolTag { TAG_FREE = 0, TAG_TRACE = 1, TAG_MISS = 2, TAG_SHADE = 3, TAG_FINISH = 4, TAG_PRIM = 5, TAG_IDLE = 6 };
 // ST_PRIM (flat traversal with RT_FLAT_PRIM_STAGE only): rays whose triangle loop was cut short, scheduled apart from fresh
 // rays so that a batch of them skips the box loop; it runs TRACE's code
@@ -136,7 +142,8 @@ RT_DEV void store_sample(float *dst, V3 L)
 #endif
 // TRAV: which traversal TRACE runs — 0 trace_threaded (any BVH), 1 trace_threaded_typed (leaves of <= 8
 // primitives), 2 trace_flat (<= 64 primitive records, nested boxes; rays with a non-finite 1/d fall back to 0),
-// 3 trace_preorder (leaves of <= 8 primitives; fixed order, ties by tabulated visiting rank)
+// 3 trace_preorder (leaves of <= 8 primitives; fixed order, ties by tabulated visiting rank), 4 trace_wide (4-wide nodes
+// collapsed from the binary tree, a quarter of the dependent fetches; rays with a non-finite 1/d fall back to 3)
 // SV: where the scene is read from — 0 global memory, 1 the whole image in LDS (256-thread workgroups, several per
 // CU), 2 nodes + escape links in LDS (SceneViewHybrid; BLOCK = 1024: one workgroup per CU shares the copy)
 template <int SV> struct PoolView;
@@ -225,11 +232,11 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         }
         // the record of an earlier call's best hit stays in the cold column unless beaten; the fixed-order walk, where
         // an equal t can still replace it, fetches it from there if (and only if) such a tie comes up
-        h.ref = (TRAV == 3 && !shadow) ? RT_REF_UNKNOWN : ((kFlatVote && cur != 0u) ? ((ct >> CT_SHIFT) & 63u) : 0u);
+        h.ref = (TRAV >= 3 && !shadow) ? RT_REF_UNKNOWN : ((kFlatVote && cur != 0u) ? ((ct >> CT_SHIFT) & 63u) : 0u);
         const float t_in = h.t;
         trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, TRAV == 2 ? (kFlatVote ? P.flat_quorum : 0u) : P.descend_quorum,
-                             cur, h, &COLD(C_REF, slot), n_work, flat_rem);
-        const bool found = TRAV == 3 ? (h.ref != RT_REF_UNKNOWN) : (h.t < t_in); // this call found a closer (or earlier-ranked) hit
+                             cur, h, &COLD(C_REF, slot), n_work, flat_rem, TRAV == 4 ? &G[C_WIDE_STATE * POOL + slot] : nullptr, POOL, P.stop_quorum);
+        const bool found = TRAV >= 3 ? (h.ref != RT_REF_UNKNOWN) : (h.t < t_in); // this call found a closer (or earlier-ranked) hit
         // (a shadow ray that is cut short with a hit in hand is done whatever the flags say: only did_hit is read)
         const bool done = cur == RT_END || (kFlatVote && shadow && h.t < RT_INFINITY);
         if (!done && kFlatVote) { // flat traversal cut short: the triangles left, best t and record (a shadow ray has none: any hit ends it)

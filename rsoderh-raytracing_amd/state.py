@@ -23,7 +23,7 @@ _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "r
             "rsrt_upload_environment", "rsrt_set_partition", "rsrt_accumulator_resize", "rsrt_accumulator_bind",
             "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_render",
             "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters", "rsrt_display_srgb8",
-            "rsrt_selftest_numerics", "rsrt_build_id",
+            "rsrt_selftest_numerics", "rsrt_build_id", "rsrt_wide_tree_build", "rsrt_build_bvh_device",
             "rsrt_partition_owner", "rsrt_partition_mask", "rsrt_partition_tiles", "rsrt_comm_available", "rsrt_comm_unique_id", "rsrt_comm_init", "rsrt_comm_reduce", "rsrt_comm_destroy",
             "rsrt_multi_create", "rsrt_multi_destroy", "rsrt_multi_last_error", "rsrt_multi_size", "rsrt_multi_context",
             "rsrt_multi_upload_scene", "rsrt_multi_upload_environment", "rsrt_multi_resize", "rsrt_multi_clear", "rsrt_multi_render",
@@ -302,6 +302,18 @@ class State:
         out = np.zeros(4, np.uint64)
         self._check(self._L.rsrt_selftest_numerics(self._ctx, _p(out)), "rsrt_selftest_numerics")
         return {"mismatches": int(out[0]), "short_path_inputs": int(out[1]), "bare_rcp_wrong": int(out[2]), "first_bad": int(out[3])}
+
+    def build_bvh_device(self, spheres, plane_descs, vertices, triangles):
+        """build_bvh on the device (rsrt_build_bvh_device): (primitives, nodes, depth, device milliseconds) — the host
+        builder's arrays, bit for bit."""
+        sph, pls = np.ascontiguousarray(spheres).view(T.SPHERE).reshape(-1), np.ascontiguousarray(plane_descs).view(T.PLANE_DESC).reshape(-1)
+        ver, tri = np.ascontiguousarray(vertices).view(T.VEC3).reshape(-1), np.ascontiguousarray(triangles).view(T.TRIANGLE).reshape(-1)
+        n = len(sph) + len(pls) + len(tri)
+        prims, nodes = np.zeros(max(n, 1), T.PRIMITIVE_INFO), np.zeros(max(2 * n, 1), T.BVH_NODE)
+        n_nodes, depth, ms = C.c_uint32(0), C.c_uint32(0), C.c_double(0.0)
+        self._check(self._L.rsrt_build_bvh_device(self._ctx, _p(sph), len(sph), _p(pls), len(pls), _p(ver), len(ver), _p(tri), len(tri), _p(prims), _p(nodes),
+                                                  C.byref(n_nodes), C.byref(depth), C.byref(ms)), "rsrt_build_bvh_device")
+        return prims[:n], nodes[:n_nodes.value].copy(), depth.value, ms.value
 
     def cast_rays(self, origins, directions, mode=0, flags=0):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)

@@ -15,16 +15,35 @@ def committed():
         return json.load(f)
 
 
+def house_counts():
+    """The counting oracle (liboracle_ops.so) on a small frame of the bench workload: f32 / u32 operations per path."""
+    import oracle
+    import rsoderh_raytracing_amd as R
+    sc = R.Scene.load_toml(util.scene_path("house"))
+    _, c = oracle.render(util.oracle_scene(sc), util.oracle_env(util.small_env()), sc.camera_uniform().view(oracle.CAMERA), 96, 54, 0, 1, 8,
+                         flags=oracle.FLAG_ANYHIT_SHADOW, fast="ops")
+    c["leaf_boxes"] = int((sc.bvh_nodes["primitives_len"] > 0).sum())
+    return c
+
+
 def test_roofline_object_is_a_fraction_of_the_valu_roof():
     c = committed()
     pmc = {k: c[k] for k in ("counters", "resolve", "kernel", "build_id", "launch_ms_under_pmc")}
     pmc["source"] = "committed"
     paths = 1920 * 1080 * 256
-    ro = bench.roofline_object(pmc, c["build_id"], 114.0, paths, c["algorithmic_bytes_per_path"], 1920 * 1080, 256)
-    assert ro["bound"] == "valu" and ro["unit"].startswith("f32 lane-instructions")
-    assert 0.0 < ro["frac"] <= 1.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+    counts = house_counts()
+    ro = bench.roofline_object(pmc, c["build_id"], 114.0, paths, c["algorithmic_bytes_per_path"], 1920 * 1080, 256, counts)
+    assert ro["bound"] == "valu" and ro["unit"] == "T lane-operations/s"
+    # frac: ALGORITHMIC operations (counted by the oracle) against the peak; utilisation: the kernel's own retired lane-instructions
+    assert 0.0 < ro["frac"] <= ro["utilisation"] <= 1.0
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12 and abs(ro["peak"] - 78.64) < 0.01
+    assert abs(ro["overhead"] - (1.0 - ro["frac"] / ro["utilisation"])) < 1e-12 and 0.0 <= ro["overhead"] < 1.0
+    w = ro["work"]
+    assert 2000 < w["f32_ops_per_path"] < 5000 and 100 < w["u32_ops_per_path"] < 1000  # house, 8 bounces: ~3,100 + ~340
+    assert abs(ro["achieved"] * 1e12 * 0.114 / paths - (w["f32_ops_per_path"] + w["u32_ops_per_path"])) < 1e-6
+    assert 8.0 < w["reference_walk_nodes_per_ray"] < w["flat_loop_leaf_boxes_per_ray"] == 20  # the flat loop tests every leaf box
     v = ro["valu"]
-    assert abs(ro["frac"] - v["issue_frac"] * 0.5 * v["lanes_active_per_instruction"] / 32.0) < 1e-9
+    assert abs(ro["utilisation"] - v["issue_frac"] * 0.5 * v["lanes_active_per_instruction"] / 32.0) < 1e-9
     assert 0.0 < v["wall"]["frac"] <= 1.0
     assert "rt_render_pool_kernel" in ro["kernel"] and ro["counters_build_id"] == c["build_id"]
     for k in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "WRITE_SIZE", "TCC_EA0_RDREQ_128B_sum"):
@@ -37,10 +56,28 @@ def test_roofline_object_is_a_fraction_of_the_valu_roof():
     assert ro["algorithmic"]["frac_of_hbm_peak"] > 1.0  # ... which is exactly why HBM is not the roof that is reported
 
 
-def test_without_counters_the_object_says_so_and_carries_no_fraction():
+def test_without_counters_the_object_still_carries_the_algorithmic_fraction():
     ro = bench.roofline_object(None, "0123456789abcdef", 114.0, 1.0e6, 3450.0, 1000, 256)
-    assert ro["frac"] is None and ro["achieved"] is None and "no PMC counters" in ro["note"]
+    assert ro["frac"] is None and ro["achieved"] is None and ro["utilisation"] is None and "no PMC counters" in ro["note"]
     assert ro["algorithmic"]["bytes_per_path"] == 3450.0
+    ro = bench.roofline_object(None, "0123456789abcdef", 114.0, 1920 * 1080 * 256, 3450.0, 1000, 256, house_counts())
+    assert 0.0 < ro["frac"] < 1.0 and ro["utilisation"] is None and ro["overhead"] is None  # the numerator needs no counters, the utilisation does
+
+
+def test_the_counting_oracle_computes_the_same_image():
+    import numpy as np
+    import oracle
+    import rsoderh_raytracing_amd as R
+    sc = R.Scene.load_toml(util.scene_path("default"))
+    args = (util.oracle_scene(sc), util.oracle_env(util.small_env()), sc.camera_uniform().view(oracle.CAMERA), 48, 32, 0, 3, 10)
+    a, sa = oracle.render(*args)
+    b, sb = oracle.render(*args, fast="ops")
+    assert np.array_equal(util.bits(a), util.bits(b))
+    assert sa["f32_ops"] == 0 and sb["f32_ops"] > 1000 * sb["paths"] and sb["int_ops"] > 50 * sb["paths"]
+    assert all(sa[k] == sb[k] for k in sa if k not in ("f32_ops", "int_ops"))
+    # a known case: a camera ray that escapes at once costs the ray generation, one unpruned walk that misses the root box and the escape
+    # (no shading): far fewer operations than a path that bounces
+    assert sb["f32_ops"] / sb["paths"] > 500
 
 
 def test_committed_counters_belong_to_the_committed_kernel_sources():

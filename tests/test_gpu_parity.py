@@ -58,9 +58,9 @@ def test_matches_golden_images_bit_exact(name):
 def probe_modes(name):
     """Every way rsrt_cast_rays can run a query (include/rsrt.h): traversal 0 threaded / 1 stack / 2 typed leaf loops /
     3 flat (what house, default and cube run in production; suzanne's 968 triangles do not qualify) / 4 fixed-order walk
-    (what suzanne and anything bigger run), x scene read from global memory or from LDS as the production kernel stages
+    / 5 wide walk (4-wide nodes; what suzanne and anything bigger run), x scene read from global memory or from LDS as the production kernel stages
     it for that traversal (bit 4), x cast_ray / cast_ray_bvh (bit 0)."""
-    sels = [0, 1, 2, 4] + ([3] if name != "suzanne" else [])
+    sels = [0, 1, 2, 4, 5] + ([3] if name != "suzanne" else [])  # (5: the wide walk — every builder-made tree qualifies)
     return [(sel << 1) | lds | bvh_only for sel in sels for lds in (0, 16) for bvh_only in (0, 1)]
 
 
@@ -101,12 +101,12 @@ def test_matches_oracle_live(name, w, h, spp, mb, big_env):
     assert (st["paths"], st["ext_rays"], st["shadow_rays"]) == (ost["paths"], ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("variant,traversal", [("0", "3"), ("1", "3"), ("2", "3"), ("3", "3"), ("4", "3"), ("2", "3-noflat"), ("4", "3-noflat"), ("2", "1"), ("4", "1"), ("2", "0")])
+@pytest.mark.parametrize("variant,traversal", [("0", "4"), ("1", "4"), ("2", "4"), ("3", "4"), ("4", "4"), ("2", "4-noflat"), ("4", "4-noflat"), ("2", "3"), ("4", "3"), ("2", "3-noflat"), ("4", "3-noflat"), ("2", "1"), ("4", "1"), ("2", "0")])
 def test_every_kernel_variant_is_bit_exact(variant, traversal, big_env, monkeypatch):
     """RSRT_KERNEL: 0 = lockstep megakernel, 1/2/3 = stage-scheduled wave-pool kernel (192/160/128 slots per wave), 4 (the
     default) = one 1024-thread workgroup and one scene copy per CU for scenes that fit LDS, 192 slots per wave;
-    RSRT_TRAVERSAL caps the traversal: 3 = product (flat loop for small scenes, fixed-order walk otherwise; with
-    RSRT_FLAT=0 the fixed-order walk for small scenes too), 1 tree walk with per-type leaf loops, 0 generic tree walk.
+    RSRT_TRAVERSAL caps the traversal: 4 = product (flat loop for small scenes, wide walk otherwise; with RSRT_FLAT=0 the
+    wide walk for small scenes too), 3 = the fixed-order walk instead of the wide one, 1 tree walk with per-type leaf loops, 0 generic tree walk.
     Scheduling differs, the per-path arithmetic does not: all must give the oracle's bits."""
     monkeypatch.setenv("RSRT_KERNEL", variant)
     monkeypatch.setenv("RSRT_TRAVERSAL", traversal[0])
@@ -491,7 +491,7 @@ def test_bvh_whose_boxes_do_not_nest_keeps_the_tree_walk(big_env):
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("traversal", ["3", "3-q100", "3-noflat", "1", "0"])
+@pytest.mark.parametrize("traversal", ["4", "4-noflat", "3", "3-q100", "3-noflat", "1", "0"])
 def test_twin_records_in_different_leaves_tie_by_visiting_order(traversal, big_env, monkeypatch):
     """A sphere exists twice, with two materials, and its copies sit in DIFFERENT leaves (the builder would never do that — equal
     centroids share a leaf — so the BVH is edited by hand: the copy is appended to the last leaf, whose box and whose
@@ -591,7 +591,7 @@ def test_flat_triangle_vote_does_not_change_the_image(quorum, big_env, monkeypat
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("traversal", ["3", "3-q100", "3-noflat", "1", "0"])
+@pytest.mark.parametrize("traversal", ["4", "4-noflat", "3", "3-q100", "3-noflat", "1", "0"])
 def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_env, monkeypatch):
     """Every primitive exists three times, at the same place, with three different materials, so every hit is a
     tie of equal t between records that usually sit in different leaves.  The reference keeps the first one it
@@ -604,7 +604,7 @@ def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_en
     so "3" also checks that it is the first copy's material that shows."""
     from rsoderh_raytracing_amd import host, types as T
     monkeypatch.setenv("RSRT_TRAVERSAL", traversal[0])
-    monkeypatch.setenv("RSRT_TRACE_BUDGET", "3")
+    monkeypatch.setenv("RSRT_TRACE_BUDGET", "1" if traversal[0] == "4" else "3")  # (the wide walk counts rounds: every ray parks its stack after one)
     if traversal.endswith("noflat"):
         monkeypatch.setenv("RSRT_FLAT", "0")
     if traversal.endswith("q100"):  # the flat traversal's triangle loop cut as often as can be: ties against the hit of an earlier call
@@ -643,7 +643,7 @@ def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_en
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("hybrid,traversal", [("1", "3"), ("0", "3"), ("1", "1"), ("0", "1")])
+@pytest.mark.parametrize("hybrid,traversal", [("1", "4"), ("0", "4"), ("1", "3"), ("0", "3"), ("1", "1"), ("0", "1")])
 def test_mid_size_scene_with_nodes_in_lds_or_in_global_memory(hybrid, traversal, big_env, monkeypatch):
     """suzanne (968 triangles): too big for the LDS image; by default what its box steps touch — the pre-order nodes of
     the fixed-order walk, or the nodes and escape links of the tree walk (RSRT_TRAVERSAL=1) — is staged in LDS for one
@@ -676,7 +676,7 @@ def test_big_scene_all_global_is_bit_exact(big_env):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     hits = oracle.cast_rays(util.oracle_scene(sc), o, d, 0, 0)
     s2 = R.State.new(sc, util.small_env(), 16, 16)
-    for mode in (0 << 1, 2 << 1, 4 << 1):
+    for mode in (0 << 1, 2 << 1, 4 << 1, 5 << 1, (5 << 1) | 16):
         got = s2.cast_rays(o, d, mode, 0)
         assert np.array_equal(np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9), hits.view(np.uint32).reshape(-1, 9)), mode
     s2.close()

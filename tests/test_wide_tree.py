@@ -1,0 +1,171 @@
+"""The wide walk's tree (csrc/hip/rt_device.h trace_wide; rsrt_upload_scene builds it, rsrt_wide_tree_build exposes the same
+builder on the host): structure checks, and a CPU restatement of the walk — 4 exact child boxes per node visit, a stack of
+(first child << 4 | mask) words, primitive masks relative to the first hit leaf's record — whose closest hits must be the
+oracle's cast_ray_bvh for rays with a finite 1/d.  No GPU."""
+import ctypes as C
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+import util
+import rsoderh_raytracing_amd as R
+from rsoderh_raytracing_amd import state
+
+EMPTY = 0xFFFFFFFF
+
+
+def wide_tree(sc):
+    L = state.lib()
+    n = C.c_uint32(0)
+    prims, nodes = np.ascontiguousarray(sc.primitives), np.ascontiguousarray(sc.bvh_nodes)
+    args = (prims.ctypes.data_as(C.c_void_p), len(prims), nodes.ctypes.data_as(C.c_void_p), len(nodes))
+    rc = L.rsrt_wide_tree_build(*args, None, C.byref(n), None)
+    if rc != 0:
+        return None
+    wn = np.zeros((n.value, 8, 4), np.float32)
+    oon = np.zeros(len(prims), np.uint32)
+    assert L.rsrt_wide_tree_build(*args, wn.ctypes.data_as(C.c_void_p), C.byref(n), oon.ctypes.data_as(C.c_void_p)) == 0
+    return wn, oon
+
+
+def scenes():
+    sys.path.insert(0, util.ROOT + "/tools")
+    import make_big_scene
+    return [("house", util.scene_path("house")), ("default", util.scene_path("default")), ("suzanne", util.scene_path("suzanne")), ("grid", make_big_scene.make(4))]
+
+
+@pytest.mark.parametrize("name,path", scenes())
+def test_wide_tree_structure(name, path):
+    sc = R.Scene.load_toml(path)
+    wn, oon = wide_tree(sc)
+    w = wn.view(np.uint32)
+    n = len(wn)
+    assert sorted(oon.tolist()) == list(range(len(sc.primitives)))  # a permutation of the records
+    seen_nodes, at = np.zeros(n, int), 0
+    seen_nodes[0] = 1
+    nodes = sc.bvh_nodes
+    boxes = {(tuple(np.asarray(nd["bounds_min"])[:3].tolist()), tuple(np.asarray(nd["bounds_max"])[:3].tolist())) for nd in nodes}
+    for i in range(n):
+        wa, base, tri, pl = (int(w[i, k, 3]) for k in range(4))
+        masks = [int(w[i, 4 + k, 3]) for k in range(4)]
+        imask, first_child = wa >> 26, wa & 0x3FFFFFF
+        n_int = bin(imask).count("1")
+        assert imask == (1 << n_int) - 1 and all(m == 0 for m in masks[:n_int])  # interior slots first, and no records of their own
+        for k in range(n_int):
+            assert 0 < first_child + k < n  # consecutive children
+            seen_nodes[first_child + k] += 1
+        leaves = [k for k in range(4) if masks[k]]
+        assert leaves == list(range(n_int, n_int + len(leaves)))  # then the leaves, then nothing
+        for k in range(4):
+            box = (tuple(wn[i, 2 * k, :3].tolist()), tuple(wn[i, 2 * k + 1, :3].tolist()))
+            assert (box in boxes) if (k < n_int + len(leaves)) else box == ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0))  # an exact box of the binary tree
+        union = 0
+        for k in leaves:
+            m = masks[k]
+            lo = (m & -m).bit_length() - 1
+            ln = bin(m).count("1")
+            assert m == ((1 << ln) - 1) << lo and 1 <= ln <= 8 and not (union & m)  # a run of records, disjoint from the other leaves'
+            assert base + lo == at  # contiguous, in the order the nodes list them
+            at += ln
+            union |= m
+        if leaves:
+            assert base + 0 == at - bin(union).count("1") and union == (1 << bin(union).count("1")) - 1
+            types = [int(sc.primitives[int(oon[base + j])]["primitive_type"]) for j in range(bin(union).count("1"))]
+            assert [(tri >> j) & 1 for j in range(len(types))] == [int(t >= 2) for t in types] and tri >> len(types) == 0
+            assert [(pl >> j) & 1 for j in range(len(types))] == [int(t == 1) for t in types] and pl >> len(types) == 0
+        else:
+            assert tri == 0 and pl == 0
+    assert at == len(sc.primitives) and np.all(seen_nodes == 1)
+
+
+def walk(wn, o, d, prim_t):
+    """trace_wide for one ray; prim_t(rec) -> hit distance or < 0.  Returns (t, rec) of the closest hit (first of equals by
+    record order is NOT modelled: callers compare t)."""
+    w = wn.view(np.uint32)
+    inv = (np.float32(1.0) / d).astype(np.float32)
+    cur, grp, stack, best = 0, 0, [], (np.float32(np.inf), -1)
+    visits = 0
+    while cur is not None:
+        visits += 1
+        hm = lm = 0
+        for k in range(4):
+            a = (wn[cur, 2 * k, :3] - o) * inv
+            b = (wn[cur, 2 * k + 1, :3] - o) * inv
+            t0 = max(np.float32(0), np.minimum(a, b).max())
+            t1 = np.maximum(a, b).min()
+            if not (t0 > t1):
+                hm |= 1 << k
+                lm |= int(w[cur, 4 + k, 3])
+        wa = int(w[cur, 0, 3])
+        im = hm & (wa >> 26)
+        if lm:
+            base = int(w[cur, 1, 3])
+            p = 0
+            while lm:
+                if lm & 1:
+                    t = prim_t(base + p)
+                    if t >= 0 and t < best[0]:
+                        best = (t, base + p)
+                lm >>= 1
+                p += 1
+        if im:
+            if grp & 15:
+                stack.append(grp)
+                assert len(stack) <= 8
+            grp = ((wa & 0x3FFFFFF) << 4) | im
+        elif not (grp & 15):
+            grp = stack.pop() if stack else 0
+        if grp & 15:
+            cur = (grp >> 4) + ((grp & -grp).bit_length() - 1)
+            grp &= grp - 1
+        else:
+            cur = None
+    return best, visits
+
+
+@pytest.mark.parametrize("name,path", [s for s in scenes() if s[0] in ("default", "suzanne")])
+def test_cpu_restatement_of_the_wide_walk_finds_the_oracles_hits(name, path):
+    sc = R.Scene.load_toml(path)
+    wn, oon = wide_tree(sc)
+    osc = util.oracle_scene(sc)
+    rng = np.random.default_rng(11)
+    n = 400
+    o = (rng.uniform(-3, 3, (n, 3)) + [0, 1, 1]).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ref = oracle.cast_rays(osc, o, d, 1, 0)  # cast_ray_bvh
+    total = 0
+    for i in range(n):
+        def prim_t(rec, i=i):  # one primitive through the oracle: a scene holding that record alone in one leaf
+            old = int(oon[rec])
+            return single[old][i]
+        if i == 0:  # hit distances of every primitive alone, all rays at once (the oracle's own intersection routines)
+            single = {}
+            for old in range(len(sc.primitives)):
+                nodes1 = np.zeros(1, sc.bvh_nodes.dtype)
+                nodes1["bounds_min"][0, :3] = -1e30
+                nodes1["bounds_max"][0, :3] = 1e30
+                nodes1["primitives_or_second_child_index"], nodes1["primitives_len"] = old, 1
+                one = oracle.Scene(materials=osc.materials, spheres=osc.spheres, planes=osc.planes, vertices=osc.vertices, normals=osc.normals,
+                                   triangles=osc.triangles, prims=osc.prims, nodes=nodes1.view(oracle.BVH_NODE))
+                h = oracle.cast_rays(one, o, d, 1, 0)
+                single[old] = np.where(h["did_hit"] != 0, h["distance"], np.float32(-1))
+        (t, rec), visits = walk(wn, o[i], d[i], prim_t)
+        total += visits
+        if ref["did_hit"][i]:
+            assert rec >= 0 and t == ref["distance"][i], (i, t, ref["distance"][i])
+        else:
+            assert rec < 0
+    assert total / n < 40  # a quarter of the binary walk's box steps, roughly
+
+
+def test_trees_that_do_not_qualify_are_refused():
+    sc = R.Scene.load_toml(util.scene_path("default"))
+    nodes = sc.bvh_nodes.copy()
+    leaf = next(i for i in range(len(nodes)) if nodes[i]["primitives_len"] > 0)
+    nodes["bounds_max"][leaf, 0] += 100.0  # a child box that sticks out of its parent's
+    bad = R.Scene(sc.materials, sc.spheres, sc.plane_descs, sc.vertices, sc.normals, sc.triangles, sc.camera_desc, planes=sc.planes,
+                  primitives=sc.primitives, bvh_nodes=nodes, bvh_depth=sc.bvh_depth)
+    assert wide_tree(bad) is None

@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 3, GPU call 6: wide walk with the 64-record window — parity, timings, loop-trip counters
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r03_call6
+mkdir -p $O
+cd $R
+timeout -k 10 420 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --timeout 100 -k "ray_batch or big_scene or mid_size or every_kernel or twin or coincident or axis_parallel or random_scenes" > $O/wide_tests.txt 2>&1; echo "pytest exit $?" >> $O/wide_tests.txt
+tail -4 $O/wide_tests.txt
+grep -q "pytest exit 0" $O/wide_tests.txt || exit 1
+timeout -k 10 300 python -m pytest tests/test_bvh_device.py -m gpu -x -q -s --timeout 200 > $O/bvh_device.txt 2>&1; tail -15 $O/bvh_device.txt
+timeout -k 10 300 python tools/bvh_knobs.py "RSRT_TRAVERSAL=3;RSRT_TRAVERSAL=4;RSRT_TRAVERSAL=4,RSRT_TRACE_BUDGET=2;RSRT_TRAVERSAL=4,RSRT_TRACE_BUDGET=8;RSRT_TRAVERSAL=4,RSRT_STOP_QUORUM=60;RSRT_TRAVERSAL=4,RSRT_STOP_QUORUM=25;RSRT_TRAVERSAL=4,RSRT_DESCEND_QUORUM=15;RSRT_TRAVERSAL=4,RSRT_DESCEND_QUORUM=50" > $O/knobs.txt 2>&1; cat $O/knobs.txt
+for lib in $R/rsoderh-raytracing_amd/librsrt_exp_*.so; do
+  RSRT_LIB=$lib timeout -k 10 200 python tools/bvh_knobs.py "RSRT_TRAVERSAL=4;RSRT_TRAVERSAL=4,RSRT_STOP_QUORUM=60" > $O/knobs_$(basename $lib).txt 2>&1; cat $O/knobs_$(basename $lib).txt
+done
+python -c "import sys; sys.path.insert(0,'tools'); import make_big_scene; make_big_scene.make(4)"
+RSRT_TRAVERSAL=4 timeout -k 10 200 python tools/simd_efficiency.py 4 16 /tmp/rsrt_scenes/suzanne_grid_4.toml 1280 720 10 > $O/simd_grid_t4.txt 2>&1; cat $O/simd_grid_t4.txt
+RSRT_TRAVERSAL=4 timeout -k 10 200 python tools/simd_efficiency.py 4 64 suzanne 1280 720 10 > $O/simd_suzanne_t4.txt 2>&1; cat $O/simd_suzanne_t4.txt
