@@ -278,6 +278,13 @@ def roofline_object(pmc, build_id, launch_ms, paths_per_launch, per_path, owned_
                             "note": "the flat loop tests every leaf box for every ray (flat_loop_leaf_boxes_per_ray) where the reference's walk visits "
                                     "reference_walk_nodes_per_ray nodes: more box tests, bought for full lanes; that difference, the scheduler, and div / sqrt / "
                                     "transcendentals costing several instructions each are what `overhead` holds"}})
+    shares_file = os.path.join(ROOT, "profiles", "r03_house_stage_shares.json")
+    if counts is not None and counts.get("f32_ops") and os.path.exists(shares_file):  # what the non-algorithmic share consists of (instrumented build)
+        with open(shares_file) as f:
+            sh = json.load(f)
+        ro["overhead_breakdown"] = {"wave_time_shares": sh["wave_time_shares"], "taken_on_build": sh["build_id"], "workload": sh["workload"], "source": sh["source"],
+                                    "note": "census = the scheduler (stage census + compaction); GEN includes the fused first trace of the camera rays; the shares are "
+                                            "of wave time, the algorithmic operations sit inside TRACE / SHADE / MISS / GEN"}
     if pmc is None:
         ro["note"] = "no PMC counters: rocprofv3 could not run here and no committed profile matches this library's build id (frac needs none; utilisation does)"
         return ro

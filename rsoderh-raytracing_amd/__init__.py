@@ -7,7 +7,14 @@ State/Scene surface.
 
 There is no CPU fallback: `State` raises if librsrt.so or a GPU is missing.
 """
-from . import state, types  # noqa: F401
+import os as _os
+
+# pipelined single-sample calls (state.State.render, the reference's interactive mode) want four kernels of a context resident at
+# once, each on a stream of its own; HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and those that share
+# one run one after the other.  Counts only before the process's first HIP call, so it is set as early as this package can.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import state, types  # noqa: F401,E402
 from .host import AliasTable, Environment, Scene, SceneError, build_bvh, camera_uniform, plane_to_uniform  # noqa: F401
 
 __all__ = ["types", "Scene", "SceneError", "Environment", "AliasTable", "build_bvh", "camera_uniform",

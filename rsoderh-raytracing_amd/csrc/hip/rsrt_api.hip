@@ -431,6 +431,14 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// Pipelined small jobs (rsrt_context::Lane) want four kernels of one context resident at a time, each from a stream of its own; the
+// HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share one run
+// one after the other — measured: 0.85 against 0.63 ms per single-sample call.  Ask for 8, unless the host has said otherwise;
+// this only counts if it happens before the process's first HIP call (INTEGRATION.md says so to hosts that initialise HIP first).
+struct HwQueueHint {
+    HwQueueHint() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+} g_hw_queue_hint;
+
 struct Env {
     float4 *rgba = nullptr;
     uint4 *alias = nullptr;
@@ -519,10 +527,19 @@ struct rsrt_context {
         size_t cold_bytes = 0;
         hipEvent_t resolved = nullptr; // recorded after the resolve that read this lane's sample buffer last
         bool resolved_valid = false;
+        hipEvent_t traced = nullptr;   // recorded after this lane's last path-tracing kernel (asked, not waited for: is the GPU busy?)
+        bool traced_valid = false;
+        hipEvent_t caller_at = nullptr; // where the caller's stream stood when this lane's last pass was enqueued
     };
-    Lane lanes[2];
-    uint32_t next_lane = 0;
+    // Ordinary jobs use lane 0.  SMALL jobs (at most `small_paths` paths a call: the reference's one sample per
+    // frame) that arrive while an earlier kernel is still running are PIPELINED: they take turns over all four lanes and run the
+    // 256-thread form of the kernel with one workgroup per CU, so that up to four calls are resident side by side and one call's
+    // ~0.5 ms of pipeline fill and drain is covered by its neighbours' steady state (a call alone on the GPU keeps the full grid:
+    // its latency is what counts then).
+    Lane lanes[4];
+    uint32_t next_small_lane = 1;
     bool overlap = true;
+    uint64_t small_paths = 4ull << 20;
     unsigned long long *dev_stats = nullptr;
     // stats
     rsrt_stats stats{};
@@ -884,9 +901,8 @@ rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context:
                          size_t smem, size_t per_sample, uint32_t max_bounces, hipStream_t caller_stream, rsrt_context::Lane &lane)
 {
     const uint32_t tile_px = P.tile_w * P.tile_h;
-    // the path-tracing kernel: on the lane's stream, after the resolve that last read this lane's sample buffer
+    // the path-tracing kernel: on the lane's stream (behind the resolve that last read this lane's sample buffer: same stream)
     const hipStream_t stream = ctx->overlap ? lane.stream : caller_stream;
-    if (ctx->overlap && lane.resolved_valid) HIP_TRY(ctx, hipStreamWaitEvent(stream, lane.resolved, 0));
     HIP_TRY(ctx, hipEventRecord(pe.begin, stream));
     if (max_bounces > 0) {
         // chunk = one tile x samples_per_chunk samples.  Up to 8 samples per chunk (2048 paths: the
@@ -924,15 +940,30 @@ rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context:
         HIP_TRY(ctx, hipMemsetAsync(lane.sample_buf, 0, per_sample * P.sample_count, stream));
     }
     HIP_TRY(ctx, hipEventRecord(pe.traced, stream));
-    // the ordered resolve: on the caller's stream (where the accumulator's other users are), after this pass's kernel
-    if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(caller_stream, pe.traced, 0));
-    hipLaunchKernelGGL(rt_resolve_kernel, dim3((P.n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, caller_stream, P, ctx->accum);
+    if (ctx->overlap) {
+        HIP_TRY(ctx, hipEventRecord(lane.traced, stream));
+        lane.traced_valid = true;
+    }
+    // The ordered resolve, behind the kernel on the lane's stream.  It adds into the accumulator, so it comes after (a) what the
+    // caller's stream holds at this moment (a clear, a caller's own kernel on a bound accumulator) and (b) whatever the context
+    // enqueued last on any stream — the previous pass's resolve above all: samples are added in increasing order.  Nothing is
+    // put on the caller's stream that could wait there (several streams share a hardware queue: a wait parked in the caller's
+    // queue holds up the lane that shares it — measured, 0.81 against 0.60 ms per single-sample call); the caller's stream is
+    // ordered behind the resolve by rsrt_render once per call, if the caller named a stream of its own.
+    if (ctx->overlap) {
+        HIP_TRY(ctx, hipEventRecord(lane.caller_at, caller_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(stream, lane.caller_at, 0));
+        if (ctx->last_valid && ctx->last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->last_event, 0));
+    }
+    hipLaunchKernelGGL(rt_resolve_kernel, dim3((P.n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, P, ctx->accum);
     HIP_TRY(ctx, hipGetLastError());
     ctx->cum_launches++;
-    HIP_TRY(ctx, hipEventRecord(pe.end, caller_stream));
+    HIP_TRY(ctx, hipEventRecord(pe.end, stream));
     if (ctx->overlap) {
-        HIP_TRY(ctx, hipEventRecord(lane.resolved, caller_stream));
+        HIP_TRY(ctx, hipEventRecord(lane.resolved, stream));
         lane.resolved_valid = true;
+        rsrt_status st = end_work(ctx, stream); // the context's chain now ends on the lane's stream
+        if (st) return st;
     }
     return RSRT_OK;
 }
@@ -993,12 +1024,15 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     DeviceGuard g(device_index);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->last_event, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipMalloc(&ctx->lanes[0].work_counter, sizeof(unsigned int))) != hipSuccess ||
-        (e = hipMalloc(&ctx->lanes[1].work_counter, sizeof(unsigned int))) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->lanes[0].stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->lanes[1].stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->lanes[0].resolved, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->lanes[1].resolved, hipEventDisableTiming)) != hipSuccess ||
+        (e = [&] { hipError_t r = hipSuccess;
+                   for (auto &L : ctx->lanes) {
+                       if (r == hipSuccess) r = hipMalloc(&L.work_counter, sizeof(unsigned int));
+                       if (r == hipSuccess) r = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+                       if (r == hipSuccess) r = hipEventCreateWithFlags(&L.resolved, hipEventDisableTiming);
+                       if (r == hipSuccess) r = hipEventCreateWithFlags(&L.traced, hipEventDisableTiming);
+                       if (r == hipSuccess) r = hipEventCreateWithFlags(&L.caller_at, hipEventDisableTiming);
+                   }
+                   return r; }()) != hipSuccess ||
         (e = hipMalloc(&ctx->dev_stats, RT_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(ctx->dev_stats, 0, RT_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess) {
         fail(nullptr, RSRT_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -1011,6 +1045,7 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
         int v = atoi(kv);
         if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
     }
+    if (const char *sp = getenv("RSRT_SMALL_PATHS")) { long long v = atoll(sp); if (v >= 0) ctx->small_paths = (uint64_t)v; } // 0: no pipelining of small jobs (A/B)
     if (const char *ov = getenv("RSRT_OVERLAP")) ctx->overlap = atoi(ov) != 0; // 0: one set of work buffers, every kernel on the caller's stream (A/B)
     if (const char *hy = getenv("RSRT_HYBRID")) ctx->allow_hybrid = atoi(hy) != 0; // 0: mid-size scenes read everything from global memory (A/B)
     if (const char *ty = getenv("RSRT_TRAVERSAL")) ctx->max_traversal = atoi(ty); // cap: 0 generic tree walk, 1 typed leaf loops, 2 + flat small-scene loop, 3 + fixed-order walk (A/B)
@@ -1048,6 +1083,8 @@ void rsrt_context_destroy(rsrt_context *ctx)
         (void)hipFree(L.cold_state);
         (void)hipFree(L.work_counter);
         if (L.resolved) (void)hipEventDestroy(L.resolved);
+        if (L.traced) (void)hipEventDestroy(L.traced);
+        if (L.caller_at) (void)hipEventDestroy(L.caller_at);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     (void)hipFree(ctx->dev_stats);
@@ -1784,15 +1821,22 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     // measured on suzanne and the 15 k-triangle grid (profiles/r02_bvh_knobs.txt): with the quorum vote a round is short, and
     // handing the slot back to the scheduler after about one round beats running several rounds with thinning lanes
     P.trace_budget = ctx->trace_budget ? ctx->trace_budget : (trav == 4 ? 4u : (trav == 3 ? 6u : 12u)); // (wide walk: rounds, not steps)
-    const bool big = kv == 4 && sv == 1; // one workgroup per CU shares the scene copy
-    const uint32_t pool = sv == 2 ? RT_WALK_POOL : ((kv == 4 && !big) ? 160u : kVariantPool[kv]);
+    // a small job behind a kernel that is still running: the 256-thread form, one workgroup per CU, on one of four lanes (see Lane)
+    bool pipelined = false;
+    if (ctx->overlap && kv == 4 && sv == 1 && (uint64_t)P.n_slots * sample_count <= ctx->small_paths && sample_count <= pass_samples)
+        for (auto &L : ctx->lanes) pipelined = pipelined || (L.traced_valid && hipEventQuery(L.traced) == hipErrorNotReady);
+    const int kv_eff = pipelined ? 2 : kv;
+    const bool big = kv_eff == 4 && sv == 1; // one workgroup per CU shares the scene copy
+    const uint32_t pool = sv == 2 ? RT_WALK_POOL : ((kv_eff == 4 && !big) ? 160u : kVariantPool[kv_eff]);
     const uint32_t block = (sv == 2 || big) ? 1024u : (uint32_t)RT_BLOCK;
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
                                 : scene_bytes + (size_t)(block / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
-    const void *kfn = variant_function(kv, sv, trav);
-    int &bpc = ctx->blocks_per_cu[sv * 5 + trav][kv];
+    const void *kfn = variant_function(kv_eff, sv, trav);
+    int pipe_blocks = 1; // workgroups per CU of a pipelined small job: four such jobs fill a CU
+    if (const char *pb = getenv("RSRT_PIPE_BLOCKS")) { int v = atoi(pb); if (v >= 1 && v <= 4) pipe_blocks = v; } // experiment knob
+    int &bpc = pipelined ? pipe_blocks : ctx->blocks_per_cu[sv * 5 + trav][kv];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, (int)block, smem);
@@ -1803,13 +1847,16 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
 
     const size_t need_cold = kv != 0 ? (size_t)ctx->cus * bpc * (block / RT_WAVE) * pool_cold_columns(trav) * pool * sizeof(uint32_t) : 0; // cold path-state arena: one block of columns per wave that can be resident
     // the context's buffers are shared by every call: order this stream after whatever ran last (another stream's
-    // render, rsrt_accumulator_clear on the context's own stream, ...)
-    if ((st = begin_work(ctx, stream))) return st;
+    // render, rsrt_accumulator_clear on the context's own stream, ...) — with lanes, enqueue_pass orders each resolve itself
+    if (!ctx->overlap && (st = begin_work(ctx, stream))) return st;
+    rsrt_context::Lane *last_lane = nullptr;
     for (uint32_t done = 0; done < sample_count; done += pass_samples) {
         P.sample_begin = sample_begin + done;
         P.sample_count = std::min(pass_samples, sample_count - done);
-        rsrt_context::Lane &lane = ctx->lanes[ctx->overlap ? ctx->next_lane : 0u];
-        if (ctx->overlap) ctx->next_lane ^= 1u;
+        uint32_t li = 0; // ordinary jobs: lane 0, one after the other (a frame's kernel time is then its own, not its neighbour's too)
+        if (ctx->overlap && pipelined) { li = ctx->next_small_lane; ctx->next_small_lane = (li + 1u) & 3u; }
+        else ctx->next_small_lane = 1u;
+        rsrt_context::Lane &lane = ctx->lanes[li];
         if (need > lane.sample_buf_bytes || need_cold > lane.cold_bytes) { // (grow-only; a reallocation waits for everything in flight)
             if ((st = sync_all(ctx))) { (void)end_work(ctx, stream); return st; }
             if (need > lane.sample_buf_bytes) {
@@ -1834,8 +1881,12 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
             return pst;
         }
         ctx->pending_events.push_back(pe);
+        last_lane = &lane;
     }
-    return end_work(ctx, stream);
+    if (!ctx->overlap) return end_work(ctx, stream);
+    // a caller that named a stream of its own gets that stream's semantics: what it enqueues there next comes after this render
+    if (hip_stream && last_lane) HIP_TRY(ctx, hipStreamWaitEvent(stream, last_lane->resolved, 0));
+    return RSRT_OK;
 }
 
 rsrt_status rsrt_synchronize(rsrt_context *ctx)

@@ -85,7 +85,19 @@ def test_probe_refuses_a_traversal_the_scene_does_not_qualify_for():
     with pytest.raises(R.RsrtError, match="bad arguments"):
         st.cast_rays(o, d, 32, 0)
     with pytest.raises(R.RsrtError, match="bad arguments"):
+        st.cast_rays(o, d, 6 << 1, 0)
+    st.close()
+    # a tree whose boxes do not nest (a leaf box pushed out of its parent's) keeps the fixed-order walk: the wide walk is refused
+    sc = R.Scene.load_toml(util.scene_path("default"))
+    nodes = sc.bvh_nodes.copy()
+    leaf = next(i for i in range(len(nodes)) if nodes[i]["primitives_len"] > 0)
+    nodes["bounds_max"][leaf, 0] += 100.0
+    bad = R.Scene(sc.materials, sc.spheres, sc.plane_descs, sc.vertices, sc.normals, sc.triangles, sc.camera_desc, planes=sc.planes,
+                  primitives=sc.primitives, bvh_nodes=nodes, bvh_depth=sc.bvh_depth)
+    st = R.State.new(bad, golden_env(), 16, 16)
+    with pytest.raises(R.RsrtError, match="wide walk"):
         st.cast_rays(o, d, 5 << 1, 0)
+    st.cast_rays(o, d, 4 << 1, 0)
     st.close()
 
 
@@ -206,7 +218,7 @@ def test_random_scenes_bit_exact(big_env):
         assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
-def test_opt_in_pruning_stays_within_tolerance(big_env):
+def test_opt_in_pruning_stays_within_tolerance(big_env, monkeypatch):
     """RSRT_FLAG_PRUNE on a scene whose BVH is really walked (suzanne): fewer box / primitive tests, the same rays, an
     image within the north-star tolerance of the exact one (it is NOT exactly result-preserving: include/rsrt.h).
     On the scenes that run the flat loop (house, default, cube) the flag has nothing to act on."""
@@ -215,7 +227,13 @@ def test_opt_in_pruning_stays_within_tolerance(big_env):
     b, sb = gpu_render(sc, big_env, 160, 90, 0, 8, 10, R.state.FLAG_PRUNE)
     assert np.all(util.rmse_per_channel(a, b, 8) <= RMSE_TOL)
     assert (sa["ext_rays"], sa["shadow_rays"]) == (sb["ext_rays"], sb["shadow_rays"])
-    assert 0 < sb["traversal_steps"] < 0.95 * sa["traversal_steps"], (sa["traversal_steps"], sb["traversal_steps"])  # measured: 0.917
+    # the flag selects the near-child-first tree walk: its steps are counted against the SAME walk without pruning (the wide
+    # walk the unflagged render takes counts node visits, four boxes each — another unit)
+    monkeypatch.setenv("RSRT_TRAVERSAL", "1")
+    a1, sa1 = gpu_render(sc, big_env, 160, 90, 0, 8, 10)
+    assert np.array_equal(util.bits(a1), util.bits(a))
+    assert 0 < sb["traversal_steps"] < 0.95 * sa1["traversal_steps"], (sa1["traversal_steps"], sb["traversal_steps"])  # measured: 0.917
+    monkeypatch.delenv("RSRT_TRAVERSAL")
     house = R.Scene.load_toml(util.scene_path("house"))
     c, sc_ = gpu_render(house, big_env, 96, 54, 0, 4, 8)
     d, sd = gpu_render(house, big_env, 96, 54, 0, 4, 8, R.state.FLAG_PRUNE)

@@ -6,5 +6,5 @@ cp $S/bench.json $R/profiles/${T}_bench.json
 cp $S/bench_under_rocprof.json $R/profiles/${T}_bench_under_rocprof.json
 cp $S/summary.txt $R/profiles/${T}_rocprofv3_summary.txt
 cp $(ls $S/trace/*/*_kernel_stats.csv | head -1) $R/profiles/${T}_kernel_stats.csv
-[ "$T" = r02_house ] && cp $S/pmc_house_1080p_8b.json $R/profiles/pmc_house_1080p_8b.json
+case "$T" in *_house) cp $S/pmc_house_1080p_8b.json $R/profiles/pmc_house_1080p_8b.json;; esac
 ls -la $R/profiles/${T}_*

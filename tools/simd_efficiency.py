@@ -28,6 +28,16 @@ print('  descend loop: wave trips %.3e, lane trips %.3e -> efficiency %.1f%% of 
 print('  leaf loop   : wave trips %.3e, lane trips %.3e -> efficiency %.1f%% ; prim tests/ray %.2f' % (c[12], c[13], 100 * c[13] / max(64 * c[12], 1), c[13] / rays))
 print('  per TRACE invocation: descend wave trips %.1f, leaf wave trips %.1f' % (c[10] / max(c[1], 1), c[12] / max(c[1], 1)))
 tot = sum(c[16:23])
+if tot:  # also as a file: bench.py attaches it to the roofline object's `overhead` (what the non-algorithmic share consists of)
+    import json
+    from rsoderh_raytracing_amd import state as S
+    shares = {n: c[16 + i] / tot for i, n in enumerate(names)}
+    shares.update(census=c[22] / tot, other=c[21] / tot)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'stage_shares_%s.json' % os.path.basename(scene).replace('.toml', '')), 'w') as f:
+        json.dump({'workload': '%s %dx%d %d spp %d bounces' % (os.path.basename(scene), w, h, spp, mb), 'build_id': S.build_id(),
+                   'wave_time_shares': shares, 'stage_lanes_of_64': {n: (c[5 + i] / c[i] if c[i] else None) for i, n in enumerate(names)},
+                   'source': 'tools/simd_efficiency.py: instrumented build (librsrt_instr.so), s_memtime stamps of lane 0 between the stages'}, f, indent=1)
 if tot:
     print('  wave-time shares (s_memtime, lane 0): ' + '  '.join('%s %.1f%%' % (n, 100 * c[16 + i] / tot) for i, n in enumerate(names)) +
           '  census %.1f%%  other %.1f%%' % (100 * c[22] / tot, 100 * c[21] / tot))
