@@ -48,7 +48,9 @@ LANES_PER_SIMD_CYCLE = 32.0  # wave64 VALU instruction = 2 cycles on a SIMD32 (g
 MAX_CLOCK_HZ = 2.4e9
 LDS_ARRAY_CYCLES_PER_CU_CYCLE = 1.0
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_house_1080p_8b.json")
-PMC_PASSES = [  # pass 0 is what the fraction needs; the others are reported when they succeed
+# NO TA_* / TD_* counters in any pass: a rocprofv3 --pmc run with them hung on this pool and cost a 15-minute GPU call (round 2; the
+# profiler's counter set, not a kernel of ours — avoided, not root-caused).  tools/pmc_scene.sh passes its extra lists through here.
+PMC_PASSES = [  # pass 0 is what `utilisation` needs; the others are reported when they succeed
     ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
      "SQ_BUSY_CYCLES", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"],
     ["FETCH_SIZE", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
@@ -59,7 +61,7 @@ PMC_PASSES = [  # pass 0 is what the fraction needs; the others are reported whe
 
 
 if os.environ.get("RSRT_PMC_EXTRA"):  # diagnosis: more passes, e.g. "TCP_TOTAL_CACHE_ACCESSES_sum,TCP_GATE_EN1_sum" (NOT TA_* / TD_*: they hang rocprofv3 here)
-    PMC_PASSES = PMC_PASSES + [p.split(",") for p in os.environ["RSRT_PMC_EXTRA"].split(";") if p]
+    PMC_PASSES = PMC_PASSES + [p.split(",") for p in os.environ["RSRT_PMC_EXTRA"].split(";") if p and "TA_" not in p and "TD_" not in p]
 
 
 def algorithmic_bytes(st):

@@ -9,7 +9,10 @@
  *  - The ONLY fused operations are inside dot(), cross(), mat3*vec and madd() below (WGSL
  *    permits fusing; fixing where it happens makes CPU and GPU agree).
  *  - normalize(v) = v * (1/sqrt(dot(v,v))); inverseSqrt(x) = 1/sqrt(x); length = sqrt(dot).
- *  - sin/cos/atan2/asin = include/rsrt_detmath.h (the ABI's published numeric contract).
+ *  - sin/cos/atan2/asin = include/rsrt_detmath.h (the ABI's published numeric contract).  NB: that header is SHARED with the
+ *    product — the kernels compile the very same routines — so a mistake in it is common to both sides and invisible to every
+ *    oracle-vs-kernel parity test; it is covered only by tests/test_detmath.py (<= 3.1 ulp against a float64 libm on the
+ *    ranges the integrator uses) and, end to end, by the float64 second reading in tests/test_independent_*.py.
  *  - max(a,b) = a<b?b:a ; min(a,b) = b<a?b:a ; saturate(x)=min(max(x,0),1) ; abs = sign clear.
  *  - u32(f32): NaN or <=0 -> 0, >= 4294967040 -> 4294967040 (naga's clamp), else truncation.
  *  - texture fetch = software bilinear with full f32 weights, a*(1-f)+b*f, clamp-to-edge

@@ -32,7 +32,8 @@
 #define RT_STATS_WORDS 40 // paths, ext, shadow, traversal steps + 32 diagnostic words (zero in the product build)
 #define RT_WAVE 64
 #ifndef RT_WALK_POOL
-#define RT_WALK_POOL 160u // path slots per wave of the 1024-thread walk kernels (hybrid scene view)
+#define RT_WALK_POOL 192u // path slots per wave of the 1024-thread walk kernels (hybrid scene view): measured 128 / 160 / 192 (profiles/r03_wide_walk.txt): the
+                          // bigger pool wins even where it takes LDS from the top block (15 k-triangle scene: 161 instead of 352 wide nodes staged, same time)
 #endif
 #ifndef RT_BIG_POOL
 #define RT_BIG_POOL 192u // RSRT_KERNEL=4: 1024-thread workgroups, this many slots per wave
@@ -1815,7 +1816,14 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const int trav = select_traversal(ctx, P.scene, max_bounces, flags);
     int sv = P.scene.lds_float4s != 0 ? 1 : 0;
     if (sv == 0 && kv != 0 && ctx->allow_hybrid) { // mid-size scene: what the chosen traversal's box steps touch, in LDS (the first kernel has no hybrid form)
-        const uint32_t head = trav == 4 ? ctx->hybrid_wnode_f4 : (trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4);
+        uint32_t head = trav == 4 ? ctx->hybrid_wnode_f4 : (trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4);
+        { // what fits beside the sixteen path pools: whole wide nodes / walk elements (any prefix of the top block will do); the tree walks need all of theirs
+            const size_t pools = (size_t)(1024 / RT_WAVE) * 4u * ((size_t)H_COUNT * RT_WALK_POOL + 64u);
+            const uint32_t room_f4 = (uint32_t)((160 * 1024 - pools) / sizeof(float4));
+            if (trav == 4) head = std::min(head, room_f4 / 8u * 8u);
+            else if (trav == 3) head = std::min(head, room_f4 / 2u * 2u);
+            else if (head > room_f4) head = 0u;
+        }
         if (head) { sv = 2; P.scene.lds_float4s = head; P.scene.lds_hybrid = trav == 4 ? 3u : (trav == 3 ? 2u : 1u); P.scene.lds_src = trav == 4 ? P.scene.wnodes : (trav == 3 ? P.scene.pnodes : P.scene.nodes); }
     }
     // measured on suzanne and the 15 k-triangle grid (profiles/r02_bvh_knobs.txt): with the quorum vote a round is short, and

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Diagnosis: bench.py on one scene with extra PMC passes.  bash tools/pmc_scene.sh <tag> <scene> <w> <h> <spp> <bounces> "<extra passes>"
+# NO TA_* / TD_* counters in <extra passes>: a rocprofv3 --pmc run with them hung on this pool (round 2, a 15-minute call lost); refused here.
 R=${GRAFT_REPO_ROOT:-/root/repo}
+case "$7" in *TA_*|*TD_*) echo "pmc_scene.sh: TA_* / TD_* counters hang rocprofv3 on this pool: not run"; exit 2;; esac
 TAG=$1; SCENE=$2; W=$3; H=$4; SPP=$5; MB=$6; EXTRA=$7
 mkdir -p $R/gpurun_out
 RSRT_PMC_EXTRA="$EXTRA" python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --scene $SCENE --width $W --height $H --spp $SPP --bounces $MB \
