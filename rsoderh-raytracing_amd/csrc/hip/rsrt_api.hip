@@ -1456,6 +1456,36 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.n_wnodes = (uint32_t)wide.size();
     sc.wide_ok = wide_ok ? 1u : 0u;
     sc.flat_ok = flat_ok ? 1u : 0u;
+    sc.n_cull = 0; sc.cull_always = 0xffffffffu;
+    if (flat_ok) { // the interior nodes two levels below the root and the leaves under each (rt_device.h, RT_FLAT_CULL)
+        std::vector<uint32_t> leaf_index(n_nodes, 0u);
+        for (size_t k = 0; k < leaf_nodes.size(); k++) leaf_index[leaf_nodes[k]] = (uint32_t)k;
+        std::vector<std::pair<uint32_t, uint32_t>> st{{0u, 0u}}; // node, depth
+        uint32_t always = 0u, cull_depth = 2u;
+        if (const char *cd = getenv("RSRT_CULL_DEPTH")) { int v = atoi(cd); if (v >= 1 && v <= 3) cull_depth = (uint32_t)v; } // experiment knob (2 measured best)
+        while (!st.empty()) {
+            auto [i, d] = st.back();
+            st.pop_back();
+            const rsrt_bvh_node &nd = nodes[i];
+            if (nd.primitives_len != 0) { always |= 1u << leaf_index[i]; continue; }
+            if (d == cull_depth && sc.n_cull < 8) {
+                uint32_t m = 0;
+                std::vector<uint32_t> sub{i};
+                while (!sub.empty()) {
+                    const uint32_t j = sub.back();
+                    sub.pop_back();
+                    if (nodes[j].primitives_len != 0) m |= 1u << leaf_index[j];
+                    else { sub.push_back(j + 1); sub.push_back(nodes[j].primitives_or_second_child_index); }
+                }
+                for (int k = 0; k < 3; k++) { sc.cull_min[sc.n_cull][k] = nd.bounds_min[k]; sc.cull_max[sc.n_cull][k] = nd.bounds_max[k]; }
+                sc.cull_mask[sc.n_cull++] = m;
+                continue;
+            }
+            st.push_back({i + 1, d + 1});
+            st.push_back({nd.primitives_or_second_child_index, d + 1});
+        }
+        sc.cull_always = always;
+    }
     sc.n_leaves = (uint32_t)leaf_nodes.size();
     sc.tri_mask_lo = (uint32_t)tri_mask; sc.tri_mask_hi = (uint32_t)(tri_mask >> 32);
     sc.plane_mask_lo = (uint32_t)plane_mask; sc.plane_mask_hi = (uint32_t)(plane_mask >> 32);

@@ -68,6 +68,10 @@ struct DevScene {
     uint32_t flat_ok, n_leaves;
     uint32_t tri_mask_lo, tri_mask_hi, plane_mask_lo, plane_mask_hi; // which records are triangles / planes
     const uint32_t *flat_rank; // [8 octants][16]: byte p = position of record p in that octant's depth-first visiting order
+    // two-level cull of the flat loop for COHERENT batches (GEN's fused trace; RT_FLAT_CULL): the interior nodes two levels below the
+    // root, each with the leaves under it as a mask; leaves above that level are always tested
+    float cull_min[8][3], cull_max[8][3];
+    uint32_t cull_mask[8], cull_always, n_cull;
     // fixed-order traversal (trace_preorder): its own node array — interior {min, link when hit}{max, link when missed},
     // leaf {min, first record | 1 << 31}{max, len | masks}, successor = next element — laid out top block first
     // (rsrt_upload_scene); [8 octants][n_prims] visiting ranks
@@ -487,6 +491,9 @@ RT_DEV float environment_pixel_solid_angle(float v, const DevEnv &e) // :739-749
 #endif
 #ifndef RT_FLAT_BOX_UNROLL
 #define RT_FLAT_BOX_UNROLL 4
+#endif
+#ifndef RT_FLAT_CULL
+#define RT_FLAT_CULL 1 // measured (profiles/r03_fusion_ab.txt): -4.3 .. -5.3 % on the BASELINE frame; see trace_flat
 #endif
 #ifndef RT_FLAT_TRI_PAIR
 #define RT_FLAT_TRI_PAIR 1 // flat traversal: two triangle records per trip of the triangle loop (-1.2 % on the BASELINE frame)
@@ -1166,15 +1173,33 @@ RT_DEV uint32_t flat_rank_of(const DevScene &sc, uint32_t octant, uint32_t rec)
 }
 
 template <class View>
-RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V3 inv, bool anyhit, uint32_t quorum, uint32_t &cur, unsigned long long &rem, Hit &h)
+RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V3 inv, bool anyhit, uint32_t quorum, uint32_t &cur, unsigned long long &rem, Hit &h,
+                       bool coherent = false)
 {
     // cur != 0: a ray whose triangle loop was cut short by the vote below comes back with the triangles it has not
     // tested yet (`rem`) and its best hit so far (`h`); it needs no box test.  A batch of such rays only skips the loop.
     const bool resumed = cur != 0u;
     uint32_t all_lo = 0u, all_hi = 0u;
     const uint32_t n_leaves = __ballot(!resumed) != 0ull ? sc.n_leaves : 0u; // (wave-uniform)
+    // Two-level cull for a coherent batch (the camera rays of a 16 x 4 patch that GEN has just built): a leaf's box is hit only if
+    // every ancestor's is (the containment the flat loop rests on), so the leaves under an interior node that NO lane of the wave
+    // hits need no test at all.  Wave-uniform: the group boxes come from the kernel arguments (scalar registers), the skip is a
+    // scalar branch.
+    uint32_t active = 0xffffffffu;
+    if (RT_FLAT_CULL && coherent && n_leaves != 0u) {
+        active = sc.cull_always;
+        for (uint32_t g = 0; g < sc.n_cull; g++) {
+            const float ax = (sc.cull_min[g][0] - o.x) * inv.x, bx = (sc.cull_max[g][0] - o.x) * inv.x;
+            const float ay = (sc.cull_min[g][1] - o.y) * inv.y, by = (sc.cull_max[g][1] - o.y) * inv.y;
+            const float az = (sc.cull_min[g][2] - o.z) * inv.z, bz = (sc.cull_max[g][2] - o.z) * inv.z;
+            const float t_0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz)), 0.0f);
+            const float t_1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz)), RT_INFINITY);
+            if (__ballot(!resumed & !(t_0 > t_1)) != 0ull) active |= sc.cull_mask[g];
+        }
+    }
 #pragma unroll RT_FLAT_BOX_UNROLL // (4: -1.3 % against 1 with the 1024-thread workgroups; it measured the same with 256-thread ones)
     for (uint32_t L = 0; L < n_leaves; L++) {
+        if (RT_FLAT_CULL && !((active >> L) & 1u)) continue; // (wave-uniform)
         DBG_WAVE_TICK(10);
         DBG_ADD(11, 1);
         const float4 n0 = S.flat(2u * L), n1 = S.flat(2u * L + 1u);
@@ -1664,7 +1689,7 @@ RT_DEV void trace_wide(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
 template <int TRAV, class View>
 RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, bool prune, bool anyhit, uint32_t budget, uint32_t quorum, uint32_t &cur,
                            Hit &h, const uint32_t *ref_mem, uint32_t &work, unsigned long long &flat_rem, uint32_t *wmem = nullptr, uint32_t wstride = 0,
-                           uint32_t stop_quorum = 0)
+                           uint32_t stop_quorum = 0, bool coherent = false)
 {
     if (TRAV == 4) {
         const V3 inv = rt_rcp3(d);
@@ -1689,7 +1714,7 @@ RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
         // 0 * x is NaN exactly when x is infinite or NaN (an overflowing sum only sends a ray the long way round)
         const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f;
         if (finite == 0.0f) {
-            trace_flat(DBG_ARG S, sc, o, d, inv, anyhit, quorum, cur, flat_rem, h);
+            trace_flat(DBG_ARG S, sc, o, d, inv, anyhit, quorum, cur, flat_rem, h, coherent);
         } else {
             trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, 0xffffffffu, cur, h, work);
         }

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
 #endif
     // One ray of `slot` (tag / flags word `ct`) from o along d, traced or resumed, and what the slot is left as: TRACE's body, as a
     // lambda because GEN runs it too (RT_GEN_TRACE: a new path's camera ray is traced by the lanes that have just built it).
-    auto trace_slot = [&](const uint32_t slot, const uint32_t ct, const V3 o, const V3 d) __attribute__((always_inline)) {
+    auto trace_slot = [&](const uint32_t slot, const uint32_t ct, const V3 o, const V3 d, const bool coherent) __attribute__((always_inline)) {
         const bool shadow = (ct & F_SHADOW) != 0u;
         // resume (or start: cur = root, best = INFINITY) the traversal
         Hit h;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         h.ref = (TRAV >= 3 && !shadow) ? RT_REF_UNKNOWN : ((kFlatVote && cur != 0u) ? ((ct >> CT_SHIFT) & 63u) : 0u);
         const float t_in = h.t;
         trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, TRAV == 2 ? (kFlatVote ? P.flat_quorum : 0u) : P.descend_quorum,
-                             cur, h, &COLD(C_REF, slot), n_work, flat_rem, TRAV == 4 ? &G[C_WIDE_STATE * POOL + slot] : nullptr, POOL, P.stop_quorum);
+                             cur, h, &COLD(C_REF, slot), n_work, flat_rem, TRAV == 4 ? &G[C_WIDE_STATE * POOL + slot] : nullptr, POOL, P.stop_quorum, coherent);
         const bool found = TRAV >= 3 ? (h.ref != RT_REF_UNKNOWN) : (h.t < t_in); // this call found a closer (or earlier-ranked) hit
         // (a shadow ray that is cut short with a hit in hand is done whatever the flags say: only did_hit is read)
         const bool done = cur == RT_END || (kFlatVote && shadow && h.t < RT_INFINITY);
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             }
             // the camera rays are traced here and now: the lanes are all busy, the rays of a tile are coherent, and the
             // path's first trip through the scheduler (a sixth of all its stage switches) is saved
-            if (kGenTrace && started) trace_slot(slot, (uint32_t)F_EXT | (uint32_t)TAG_TRACE, cam_o, cam_d);
+            if (kGenTrace && started) trace_slot(slot, (uint32_t)F_EXT | (uint32_t)TAG_TRACE, cam_o, cam_d, true);
             if (exhausted) { // nothing more to hand out: park every FREE slot
                 for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
                     if (lane + 64u * k < POOL && TAG_OF(lane + 64u * k) == TAG_FREE) SET_TAG(lane + 64u * k, TAG_IDLE);
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 const uint32_t dcol = (ct & F_SHADOW) ? (uint32_t)H_SX : (uint32_t)H_EX;
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
                 const V3 d = v3(HOTF(dcol, slot), HOTF(dcol + 1u, slot), HOTF(dcol + 2u, slot));
-                trace_slot(slot, ct, o, d);
+                trace_slot(slot, ct, o, d, false);
             }
         } else if (best == ST_MISS) {
             // ---------------- MISS: brute-force fallback of cast_ray (shader.wgsl:583-598), then escape

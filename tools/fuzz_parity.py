@@ -56,8 +56,13 @@ for trial in range(trials):
     sc = R.Scene(mats, sph, pls, verts, norms, tri, cam)
     w, h, spp, mb = 64, 40, 3, 5
     ref, ost = oracle.render(util.oracle_scene(sc), oenv, sc.camera_uniform().view(oracle.CAMERA), w, h, 0, spp, mb)
-    for cap in ('2', '1', '0') if trial % 5 == 0 else ('2',):
-        os.environ['RSRT_TRAVERSAL'] = cap
+    # the product's choice (flat loop / wide walk) for every scene; every 5th also through the wide walk with small scenes forced
+    # onto it and every ray parked after one round, the fixed-order walk and the two tree walks
+    for cap in ('4', '4-noflat-b1', '3-noflat', '1', '0') if trial % 5 == 0 else ('4',):
+        os.environ['RSRT_TRAVERSAL'] = cap[0]
+        os.environ['RSRT_FLAT'] = '0' if 'noflat' in cap else '1'
+        os.environ.pop('RSRT_TRACE_BUDGET', None)
+        if cap.endswith('b1'): os.environ['RSRT_TRACE_BUDGET'] = '1'
         st = R.State.new(sc, env, w, h); st.max_bounces = mb
         st.render_range(0, spp); img = st.download(); g = st.stats(); st.close()
         ok = np.array_equal(util.bits(img), util.bits(ref)) and (g['ext_rays'], g['shadow_rays']) == (ost['ext_rays'], ost['shadow_rays'])
