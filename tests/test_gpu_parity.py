@@ -2,6 +2,7 @@
 golden vectors.  Integer/index work and — because both sides evaluate the same correctly-rounded
 f32 expression trees (DESIGN.md "Numerics") — the radiance sums too are compared BIT-EXACT; the
 north-star tolerance (1e-3 per-channel RMSE) is asserted as well where stated."""
+import ctypes
 import os
 
 import numpy as np
@@ -698,3 +699,28 @@ def test_big_scene_all_global_is_bit_exact(big_env):
         got = s2.cast_rays(o, d, mode, 0)
         assert np.array_equal(np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9), hits.view(np.uint32).reshape(-1, 9)), mode
     s2.close()
+
+
+@pytest.mark.parametrize("name,w,h,spp,mb", [("house", 128, 72, 6, 8), ("default", 96, 64, 4, 10), ("suzanne", 80, 48, 3, 10)])
+def test_two_pipelines_that_share_only_the_asset_files(name, w, h, spp, mb):
+    """Every other image test feeds the oracle the product's OWN preprocessing output (tests/util.py: same BVH, same alias table, same
+    plane matrices on both sides), which would hide a mistake common to the C++ preprocessing and whatever consumes it.  Here the two
+    sides share nothing but the TOML / OBJ files and the environment's texels: the oracle side is the Python scene reader + the oracle's
+    own build_bvh / plane_to_uniform / camera_uniform / alias table (oracle/scene_py.py, rt_oracle.cpp), the product side is
+    librsrt_host's loader and builders + the alias table built ON THE DEVICE + the kernels.  Same bits."""
+    from oracle import scene_py
+    o = scene_py.load_toml(util.scene_path(name))
+    env_rgba = R.Environment.synthetic(128, 64).rgba  # (the frozen synthetic-sky formula; its texels are the shared input)
+    alias, _ = oracle.alias_table(env_rgba[..., :3])
+    ref, ost = oracle.render(o["scene"], oracle.Env(env_rgba, alias), o["camera"].view(oracle.CAMERA), w, h, 0, spp, mb)
+    sc = R.Scene.load_toml(util.scene_path(name))
+    st = R.State.new(sc, R.Environment(env_rgba.copy()), w, h)  # (host-built alias table uploaded ...)
+    L = R.state.lib()
+    L.rsrt_environment_build_alias.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    assert L.rsrt_environment_build_alias(st._ctx, 0, None, 0, None) == 0  # (... and replaced by the one the device builds from the texels)
+    st.max_bounces = mb
+    st.render_range(0, spp)
+    img, g = st.download(), st.stats()
+    st.close()
+    assert np.array_equal(util.bits(img), util.bits(ref))
+    assert (g["paths"], g["ext_rays"], g["shadow_rays"]) == (ost["paths"], ost["ext_rays"], ost["shadow_rays"])
