@@ -54,6 +54,7 @@ struct RenderParams {
     uint32_t chunk_px, n_subtiles; // a chunk covers chunk_px consecutive pixels of a tile (tile_px / n_subtiles)
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
     uint32_t trace_budget, descend_quorum, flat_quorum, stop_quorum;
+    uint32_t refill_min; // wide walk with refill: waiting rays at which TRACE is due (rt_wavepool.h, "2. which stage")
     uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
     float *sample_buf;
     unsigned int *work_counter;
@@ -112,14 +113,19 @@ __device__ __forceinline__ SceneView<false> make_view<false>(const DevScene &sc)
 
 __device__ __forceinline__ SceneViewHybrid make_view_hybrid(const DevScene &sc)
 {
-    return SceneViewHybrid{0u, 2u * sc.n_nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.pnodes, sc.lds_float4s, sc.wnodes, sc.lds_hybrid};
+    const bool wide = sc.lds_hybrid == 3u; // the wide walk's image: wide nodes | primitive records | triangle normals | materials (prefixes, DevScene)
+    const uint32_t o_p = 8u * sc.lds_wnodes, o_t = o_p + sc.lds_prims_f4, o_m = o_t + sc.lds_trin_f4;
+    return SceneViewHybrid{0u, 2u * sc.n_nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.pnodes, sc.lds_float4s, sc.wnodes, sc.lds_hybrid,
+                           wide ? sc.lds_wnodes : 0u, o_p, wide ? sc.lds_prims_f4 : 0u, o_t, wide ? sc.lds_trin_f4 : 0u, o_m, wide ? sc.lds_mats_f4 : 0u};
 }
 
 // Copies the scene image into LDS (the arrays are contiguous in one device allocation, in the order
 // make_view<true> assumes).
 __device__ __forceinline__ void stage_scene_lds(const DevScene &sc)
 {
-    for (uint32_t i = threadIdx.x; i < sc.lds_float4s; i += blockDim.x) rt_smem[i] = sc.lds_src[i];
+    // (RT_WNODE_SWIZZLE: the wide walk's nodes are stored swizzled, see SceneViewHybrid::wnode: piece k of node n sits in the node's cell k ^ (n & 7))
+    const uint32_t n_swz = (RT_WNODE_SWIZZLE && sc.lds_hybrid == 3u) ? 8u * sc.lds_wnodes : 0u;
+    for (uint32_t i = threadIdx.x; i < sc.lds_float4s; i += blockDim.x) rt_smem[i < n_swz ? (i ^ ((i >> 3) & 7u)) : i] = sc.lds_src[i];
     __syncthreads();
 }
 
@@ -312,6 +318,10 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
 }
 
 #include "rt_wavepool.h"
+// LDS of the 1024-thread walk kernels (hybrid scene view): sixteen waves' pools — with RT_HOT_GLOBAL only their tag column and compaction list —
+// and beside them the traversal's part of the scene
+static constexpr size_t kHybridPoolBytes = (size_t)(1024 / RT_WAVE) * 4u * ((size_t)(RT_HOT_GLOBAL ? 1u : (uint32_t)H_COUNT) * RT_WALK_POOL + pool_list_dwords(4));
+static constexpr uint32_t kHybridRoomF4 = (uint32_t)((160 * 1024 - kHybridPoolBytes) / sizeof(float4));
 #include "rt_alias_device.h"
 #include "rt_bvh_device.h"
 
@@ -504,7 +514,11 @@ struct rsrt_context {
     float4 *scene_blob = nullptr;
     DevScene scene{};
     bool scene_ready = false;
-    uint32_t hybrid_head_f4 = 0, hybrid_pnode_f4 = 0, hybrid_wnode_f4 = 0; // mid-size scenes: float4s of nodes + escape links / of the pre-order nodes' / the wide nodes' top block (0 = none)
+    uint32_t hybrid_head_f4 = 0, hybrid_pnode_f4 = 0; // mid-size scenes: float4s of nodes + escape links / of the pre-order nodes' top block (0 = none)
+    // ... and the wide walk's LDS image, a copy at the end of scene_blob: the first wimg_nodes wide nodes | the first wimg_prims_f4 / 4 primitive
+    // records | all triangle normals | all materials, as far as kHybridRoomF4 goes in that order (0 nodes = no image)
+    const float4 *wide_image = nullptr;
+    uint32_t wimg_nodes = 0, wimg_prims_f4 = 0, wimg_trin_f4 = 0, wimg_mats_f4 = 0;
     // environments
     std::vector<Env> envs;
     // partition
@@ -576,6 +590,7 @@ struct rsrt_context {
     bool allow_hybrid = true;
     uint32_t trace_budget = 0; // traversal steps per TRACE invocation before a ray is re-queued (0: 6 for the fixed-order walk, 12 for the tree walks)
     uint32_t descend_quorum = 30; // fixed-order / wide walk: a descending round ends once fewer than this percentage of its lanes are still descending
+    uint32_t refill_min = 96;  // wide walk with refill: TRACE is due once this many rays wait for it (RSRT_REFILL_MIN)
     uint32_t stop_quorum = 40; // wide walk: a TRACE call ends (the unfinished rays park their stacks) once fewer than this percentage of its lanes are still walking
     uint32_t chunks_per_wave = 32; // work chunks a resident wave should get at least (RSRT_CHUNKS_PER_WAVE): sets samples per chunk, and sub-tiles for small jobs
     uint32_t flat_quorum = 20; // flat traversal: the triangle loop ends once fewer than this percentage of its lanes still hold triangles (0: never)
@@ -884,6 +899,44 @@ rsrt_status collect_stats(rsrt_context *ctx)
 }
 
 
+// Mid-size and big scenes (no whole image in LDS): what the chosen traversal keeps in LDS beside the pools (SceneViewHybrid) — the wide walk
+// (trav 4) its image of nodes | records | shading arrays, the fixed-order walk (3) the top block of its elements (any prefix will do), the
+// tree walks their nodes + escape links (all or nothing).  Sets the scene's lds_* fields; false: nothing is staged.
+static bool hybrid_stage(const rsrt_context *ctx, DevScene &sc, int trav, uint32_t room_f4)
+{
+    sc.lds_wnodes = sc.lds_prims_f4 = sc.lds_trin_f4 = sc.lds_mats_f4 = 0u;
+    if (trav == 4) {
+        if (ctx->wimg_nodes == 0) return false;
+        // (the image was cut for kHybridRoomF4 at upload; a caller with less room — the probe with a deep stack — takes what fits, nodes first)
+        sc.lds_wnodes = std::min(ctx->wimg_nodes, room_f4 / 8u);
+        if (sc.lds_wnodes == 0) return false;
+        if (sc.lds_wnodes == ctx->wimg_nodes) {
+            room_f4 -= 8u * sc.lds_wnodes;
+            sc.lds_prims_f4 = std::min(ctx->wimg_prims_f4, room_f4 / 4u * 4u);
+            if (sc.lds_prims_f4 == ctx->wimg_prims_f4) {
+                room_f4 -= sc.lds_prims_f4;
+                if (ctx->wimg_trin_f4 <= room_f4) {
+                    sc.lds_trin_f4 = ctx->wimg_trin_f4;
+                    room_f4 -= sc.lds_trin_f4;
+                    if (ctx->wimg_mats_f4 <= room_f4) sc.lds_mats_f4 = ctx->wimg_mats_f4;
+                }
+            }
+        }
+        sc.lds_float4s = 8u * sc.lds_wnodes + sc.lds_prims_f4 + sc.lds_trin_f4 + sc.lds_mats_f4;
+        sc.lds_hybrid = 3u;
+        sc.lds_src = ctx->wide_image;
+        return true;
+    }
+    uint32_t head = trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4;
+    if (trav == 3) head = std::min(head, room_f4 / 2u * 2u);
+    else if (head > room_f4) head = 0u;
+    if (head == 0u) return false;
+    sc.lds_float4s = head;
+    sc.lds_hybrid = trav == 3 ? 2u : 1u;
+    sc.lds_src = trav == 3 ? sc.pnodes : sc.nodes;
+    return true;
+}
+
 // Which traversal TRACE runs (rt_wavepool.h, TRAV): the flat loop where the scene qualifies, else the fixed-order walk,
 // else (leaves longer than 8 primitives) the generic tree walk; RSRT_TRAVERSAL / RSRT_FLAT cap the choice for A/B runs.
 int select_traversal(const rsrt_context *ctx, const DevScene &sc, uint32_t max_bounces, uint32_t flags)
@@ -1054,6 +1107,7 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
     if (const char *dq = getenv("RSRT_DESCEND_QUORUM")) { int v = atoi(dq); if (v >= 0 && v <= 100) ctx->descend_quorum = (uint32_t)v; }
     if (const char *sq = getenv("RSRT_STOP_QUORUM")) { int v = atoi(sq); if (v >= 0 && v <= 100) ctx->stop_quorum = (uint32_t)v; }
+    if (const char *rm = getenv("RSRT_REFILL_MIN")) { int v = atoi(rm); if (v >= 1 && v <= 4096) ctx->refill_min = (uint32_t)v; }
     if (const char *cw = getenv("RSRT_CHUNKS_PER_WAVE")) { int v = atoi(cw); if (v >= 1 && v <= 4096) ctx->chunks_per_wave = (uint32_t)v; }
     if (const char *fq = getenv("RSRT_FLAT_QUORUM")) { int v = atoi(fq); if (v >= 0 && v <= 100) ctx->flat_quorum = (uint32_t)v; }
     for (int m = 0; m < 18; m++) (void)hipFuncSetAttribute(probe_function(m / 6, m % 6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1298,7 +1352,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
             }
         }
     }
-    const uint32_t kTopMax = 1408; // top-block elements that fit beside sixteen path pools: 1408 x 32 B = 44 KB
+    const uint32_t kTopMax = kHybridRoomF4 / 2u; // top-block elements that fit beside sixteen path pools (32 B each)
     std::vector<PNode> plist;
     uint32_t top_elems = 0;
     for (uint32_t want = std::min<uint32_t>(n_nodes, kTopMax);; want = want * 7 / 8) {
@@ -1347,9 +1401,22 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     for (uint32_t e = 0; e < n_pnodes; e++)
         if (plist[e].old != 0xffffffffu) new_id[plist[e].old] = e;
     const size_t pnode_f4 = 2ull * n_pnodes, prank_f4 = (8ull * n_primitives + 3) / 4, wnode_f4 = 8ull * wide.size();
+    // the wide walk's LDS image: what a ray gathers per lane — nodes first, then primitive records, then the shading arrays — as far as the room goes
+    uint32_t wimg_nodes = 0, wimg_prims_f4 = 0, wimg_trin_f4 = 0, wimg_mats_f4 = 0;
+    if (wide_ok) {
+        uint32_t room = kHybridRoomF4;
+        wimg_nodes = std::min<uint32_t>((uint32_t)wide.size(), room / 8u);
+        room -= 8u * wimg_nodes;
+        if (!RT_HOT_GLOBAL) room = 0u; // (the hybrid view reads nothing but nodes from LDS then)
+        wimg_prims_f4 = 4u * std::min<uint32_t>(n_primitives, room / 4u);
+        room -= wimg_prims_f4;
+        if (wimg_prims_f4 == 4u * n_primitives && 3ull * n_triangles <= room) { wimg_trin_f4 = 3u * n_triangles; room -= wimg_trin_f4; }
+        if (wimg_prims_f4 == 4u * n_primitives && 4ull * n_materials <= room) { wimg_mats_f4 = 4u * n_materials; room -= wimg_mats_f4; }
+    }
+    const size_t wimg_f4 = 8ull * wimg_nodes + wimg_prims_f4 + wimg_trin_f4 + wimg_mats_f4;
     // ---- build the device image: nodes | prims | escape links | tri normals | materials | fb spheres | fb planes
     const size_t n_f4 = 2ull * n_nodes + 4ull * n_primitives + 3ull * n_triangles + 4ull * n_materials + 4ull * n_spheres + 4ull * n_planes + esc_f4 + flat_f4;
-    std::vector<float4> img(n_f4 + rank_f4 + pnode_f4 + prank_f4 + wnode_f4); // what follows the LDS image: flat ranks | pre-order nodes | record ranks | wide nodes
+    std::vector<float4> img(n_f4 + rank_f4 + pnode_f4 + prank_f4 + wnode_f4 + wimg_f4); // what follows the LDS image: flat ranks | pre-order nodes | record ranks | wide nodes | the wide walk's LDS image
     float4 *p = img.data();
     float4 *p_nodes = p;
     bool typed_leaves = true;
@@ -1433,6 +1500,16 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     }
     if (n_primitives) memcpy(p_pnodes + pnode_f4, prim_rank.data(), prim_rank.size() * sizeof(uint32_t));
     fill_wide_nodes(wide, nodes, primitives, p_pnodes + pnode_f4 + prank_f4);
+    { // the wide walk's LDS image: copies of the arrays' heads, in the order SceneViewHybrid expects
+        float4 *q = p_pnodes + pnode_f4 + prank_f4 + wnode_f4;
+        if (wimg_nodes) memcpy(q, p_pnodes + pnode_f4 + prank_f4, 8ull * wimg_nodes * sizeof(float4));
+        q += 8ull * wimg_nodes;
+        if (wimg_prims_f4) memcpy(q, p_prims, (size_t)wimg_prims_f4 * sizeof(float4));
+        q += wimg_prims_f4;
+        if (wimg_trin_f4) memcpy(q, p_trin, (size_t)wimg_trin_f4 * sizeof(float4));
+        q += wimg_trin_f4;
+        if (wimg_mats_f4) memcpy(q, p_mats, (size_t)wimg_mats_f4 * sizeof(float4));
+    }
 
     { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     if (ctx->scene_blob) { (void)hipFree(ctx->scene_blob); ctx->scene_blob = nullptr; }
@@ -1455,6 +1532,9 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.wnodes = ctx->scene_blob + n_f4 + rank_f4 + pnode_f4 + prank_f4;
     sc.n_wnodes = (uint32_t)wide.size();
     sc.wide_ok = wide_ok ? 1u : 0u;
+    sc.lds_wnodes = sc.lds_prims_f4 = sc.lds_trin_f4 = sc.lds_mats_f4 = 0u; // (set per launch, hybrid_stage)
+    ctx->wide_image = ctx->scene_blob + n_f4 + rank_f4 + pnode_f4 + prank_f4 + wnode_f4;
+    ctx->wimg_nodes = wimg_nodes; ctx->wimg_prims_f4 = wimg_prims_f4; ctx->wimg_trin_f4 = wimg_trin_f4; ctx->wimg_mats_f4 = wimg_mats_f4;
     sc.flat_ok = flat_ok ? 1u : 0u;
     sc.n_cull = 0; sc.cull_always = 0xffffffffu;
     if (flat_ok) { // the interior nodes two levels below the root and the leaves under each (rt_device.h, RT_FLAT_CULL)
@@ -1498,11 +1578,12 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.lds_float4s = (n_f4 * sizeof(float4) <= 24 * 1024) ? (uint32_t)n_f4 : 0u; // whole image in LDS only while it leaves room for the path pools
     sc.lds_hybrid = 0;
     sc.lds_src = sc.nodes; // the image starts with the nodes
-    ctx->hybrid_head_f4 = ctx->hybrid_pnode_f4 = ctx->hybrid_wnode_f4 = 0;
+    ctx->hybrid_head_f4 = ctx->hybrid_pnode_f4 = 0;
     if (sc.lds_float4s == 0) { // mid-size: what every box step touches goes to LDS, one big workgroup per CU shares the copy
-        if (traversal_head_f4 * sizeof(float4) <= 40 * 1024) ctx->hybrid_head_f4 = (uint32_t)traversal_head_f4; // nodes + escape links (tree walks)
+        if (traversal_head_f4 * sizeof(float4) <= 40 * 1024) ctx->hybrid_head_f4 = (uint32_t)traversal_head_f4; // nodes + escape links (tree walks; the render call checks the room beside its pools)
         ctx->hybrid_pnode_f4 = 2u * top_elems; // the top block of the fixed-order walk's nodes (all of them when the scene is mid-size)
-        ctx->hybrid_wnode_f4 = 8u * std::min<uint32_t>((uint32_t)wide.size(), kTopMax / 4u); // the wide walk's: breadth-first order puts the top of the tree first
+    } else {
+        ctx->wimg_nodes = 0; // (a small scene runs from its whole image)
     }
     memset(ctx->blocks_per_cu, 0, sizeof ctx->blocks_per_cu); // the kernels' dynamic LDS size depends on the scene: occupancy is asked for again
     ctx->scene_ready = true;
@@ -1831,6 +1912,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.descend_quorum = ctx->descend_quorum;
     P.flat_quorum = ctx->flat_quorum;
     P.stop_quorum = ctx->stop_quorum;
+    P.refill_min = ctx->refill_min;
     P.stats = ctx->dev_stats;
     if (P.n_slots == 0) return RSRT_OK;
 
@@ -1846,15 +1928,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const int trav = select_traversal(ctx, P.scene, max_bounces, flags);
     int sv = P.scene.lds_float4s != 0 ? 1 : 0;
     if (sv == 0 && kv != 0 && ctx->allow_hybrid) { // mid-size scene: what the chosen traversal's box steps touch, in LDS (the first kernel has no hybrid form)
-        uint32_t head = trav == 4 ? ctx->hybrid_wnode_f4 : (trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4);
-        { // what fits beside the sixteen path pools: whole wide nodes / walk elements (any prefix of the top block will do); the tree walks need all of theirs
-            const size_t pools = (size_t)(1024 / RT_WAVE) * 4u * ((size_t)H_COUNT * RT_WALK_POOL + 64u);
-            const uint32_t room_f4 = (uint32_t)((160 * 1024 - pools) / sizeof(float4));
-            if (trav == 4) head = std::min(head, room_f4 / 8u * 8u);
-            else if (trav == 3) head = std::min(head, room_f4 / 2u * 2u);
-            else if (head > room_f4) head = 0u;
-        }
-        if (head) { sv = 2; P.scene.lds_float4s = head; P.scene.lds_hybrid = trav == 4 ? 3u : (trav == 3 ? 2u : 1u); P.scene.lds_src = trav == 4 ? P.scene.wnodes : (trav == 3 ? P.scene.pnodes : P.scene.nodes); }
+        if (hybrid_stage(ctx, P.scene, trav, kHybridRoomF4)) sv = 2;
     }
     // measured on suzanne and the 15 k-triangle grid (profiles/r02_bvh_knobs.txt): with the quorum vote a round is short, and
     // handing the slot back to the scheduler after about one round beats running several rounds with thinning lanes
@@ -1868,8 +1942,9 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const uint32_t pool = sv == 2 ? RT_WALK_POOL : ((kv_eff == 4 && !big) ? 160u : kVariantPool[kv_eff]);
     const uint32_t block = (sv == 2 || big) ? 1024u : (uint32_t)RT_BLOCK;
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
+    const bool hot_global = RT_HOT_GLOBAL && sv == 2; // the walk kernels keep only the tag column of the hot path state in LDS (rt_wavepool.h)
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
-                                : scene_bytes + (size_t)(block / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + 64u);
+                                : scene_bytes + (size_t)(block / RT_WAVE) * 4u * ((size_t)(hot_global ? 1u : (uint32_t)H_COUNT) * pool + pool_list_dwords(trav));
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
     const void *kfn = variant_function(kv_eff, sv, trav);
     int pipe_blocks = 1; // workgroups per CU of a pipelined small job: four such jobs fill a CU
@@ -1883,7 +1958,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         if (const char *o = getenv("RSRT_BLOCKS_PER_CU")) { int v = atoi(o); if (v > 0) bpc = std::min(bpc, v); } // experiment knob
     }
 
-    const size_t need_cold = kv != 0 ? (size_t)ctx->cus * bpc * (block / RT_WAVE) * pool_cold_columns(trav) * pool * sizeof(uint32_t) : 0; // cold path-state arena: one block of columns per wave that can be resident
+    const size_t need_cold = kv != 0 ? (size_t)ctx->cus * bpc * (block / RT_WAVE) * (pool_cold_columns(trav) + (hot_global ? (uint32_t)H_CT : 0u)) * pool * sizeof(uint32_t) : 0; // cold path-state arena: one block of columns per wave that can be resident
     // the context's buffers are shared by every call: order this stream after whatever ran last (another stream's
     // render, rsrt_accumulator_clear on the context's own stream, ...) — with lanes, enqueue_pass orders each resolve itself
     if (!ctx->overlap && (st = begin_work(ctx, stream))) return st;
@@ -2016,9 +2091,12 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
         if (sc.lds_float4s != 0) {
             sv = 1;
         } else {
-            const uint32_t head = trav == 5 ? ctx->hybrid_wnode_f4 : (trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4);
-            if (head == 0) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: this scene is not staged in LDS by the production kernel");
-            sv = 2; sc.lds_float4s = head; sc.lds_hybrid = trav == 5 ? 3u : (trav == 3 ? 2u : 1u); sc.lds_src = trav == 5 ? sc.wnodes : (trav == 3 ? sc.pnodes : sc.nodes);
+            // (what the production kernel stages for that traversal — the probe has no pools beside it; only the stack walk needs a stack)
+            const uint32_t all_f4 = 160u * 1024u / (uint32_t)sizeof(float4);
+            const uint32_t stack_f4 = trav == 4 ? (uint32_t)(((size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t) + 15u) / 16u) : 0u;
+            if (!hybrid_stage(ctx, sc, trav == 5 ? 4 : (trav == 4 ? 0 : trav), all_f4 > stack_f4 ? all_f4 - stack_f4 : 0u))
+                return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: this scene is not staged in LDS by the production kernel");
+            sv = 2;
         }
     } else {
         sc.lds_float4s = 0;
@@ -2035,7 +2113,7 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
     if (e == hipSuccess) e = hipMemcpy(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_d, dirs, (size_t)n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        const size_t smem = (size_t)sc.lds_float4s * sizeof(float4) + (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t);
+        const size_t smem = (size_t)sc.lds_float4s * sizeof(float4) + (trav == 4 ? (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t) : 0u); // (only the stack walk has a stack)
         if (smem > 160 * 1024) { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: needs %zu bytes of LDS", smem); }
         uint32_t repeat = 1;
         if (const char *pr = getenv("RSRT_PROBE_REPEAT")) { int v = atoi(pr); if (v > 1 && v <= 4096) repeat = (uint32_t)v; }

@@ -84,6 +84,9 @@ struct DevScene {
     // which of the 32 records from there are triangles / planes, [4 + k] slot k's records as a mask from there (0: not a leaf)
     const float4 *wnodes;
     uint32_t n_wnodes, wide_ok;
+    // the wide walk's LDS image (lds_hybrid == 3; rsrt_api.hip, wide_image): the first lds_wnodes wide nodes, then the first lds_prims_f4 / 4
+    // primitive records, then ALL triangle normals and ALL materials if they still fit (0 = none staged); everything else is read from global memory
+    uint32_t lds_wnodes, lds_prims_f4, lds_trin_f4, lds_mats_f4;
     const float4 *lds_src; // what stage_scene_lds copies (lds_float4s float4s): the image, nodes | escape links, or the pre-order nodes
 };
 
@@ -102,6 +105,14 @@ template <bool LDS>
 struct SceneView;
 
 extern __shared__ float4 rt_smem[];
+// RT_HOT_GLOBAL (rt_wavepool.h): the walk kernels keep only the tag column of the hot path state in LDS and stage nodes, primitive records, normals
+// and materials there instead.  Measured (profiles/r03_hot_global.txt): not faster — 0: the hybrid view stages wide nodes only, the rest is global
+#ifndef RT_HOT_GLOBAL
+#define RT_HOT_GLOBAL 0
+#endif
+#ifndef RT_WNODE_SWIZZLE
+#define RT_WNODE_SWIZZLE 0 // the wide walk's LDS nodes: piece k of node n in cell k ^ (n & 7) (bank conflicts, SceneViewHybrid::wnode; measured, not faster)
+#endif
 
 template <>
 struct SceneView<true> {
@@ -117,6 +128,12 @@ struct SceneView<true> {
     RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
     RT_DEV float4 flat(uint32_t i) const { return rt_smem[o_flat + i]; }
     RT_DEV float4 prim(uint32_t i) const { return rt_smem[o_prims + i]; }
+    template <int N>
+    RT_DEV void prim_rec(uint32_t rec, float4 (&r)[N]) const
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = rt_smem[o_prims + 4u * rec + (uint32_t)k];
+    }
     RT_DEV float4 trin(uint32_t i) const { return rt_smem[o_trin + i]; }
     RT_DEV float4 mat(uint32_t i) const { return rt_smem[o_mats + i]; }
     // record k of the primitive array named by src (SRC_BVH / SRC_FB_SPHERE / SRC_FB_PLANE)
@@ -140,6 +157,12 @@ struct SceneView<false> {
     RT_DEV float4 node(uint32_t i) const { return nodes[i]; }
     RT_DEV float4 flat(uint32_t i) const { return flat_leaves[i]; }
     RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
+    template <int N>
+    RT_DEV void prim_rec(uint32_t rec, float4 (&r)[N]) const
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = prims[4u * rec + (uint32_t)k];
+    }
     RT_DEV float4 trin(uint32_t i) const { return tri_normals[i]; }
     RT_DEV float4 mat(uint32_t i) const { return materials[i]; }
     RT_DEV float4 rec(uint32_t src, uint32_t i) const
@@ -159,24 +182,33 @@ struct SceneViewHybrid {
     uint32_t lds_f4;
     const float4 *wnodes;
     uint32_t head; // what the staged head holds (DevScene::lds_hybrid): the accessors of the other traversals read global memory
-    // Wide node i: from LDS when it is in the top block (the first lds_f4 / 8 nodes: breadth-first order puts the top of the
-    // tree there), else from global memory; same shape as pnode_pair below (unconditional ds_reads + global loads under a branch)
+    // head == 3, the wide walk's image: [wide nodes][primitive records][triangle normals][materials], each a PREFIX of its array (0: none)
+    uint32_t n_w, o_p, n_p_f4, o_t, n_t_f4, o_m, n_m_f4;
+    // One array element: from LDS when it lies in the staged prefix, else from global memory.  Written as an unconditional ds_read (of
+    // element 0 for the lanes that are past the prefix) plus a global load under a branch: a select between the two POINTERS makes the
+    // compiler emit flat loads, which take the texture path even for LDS and are waited for one by one (measured on the fixed-order
+    // walk: 12 % slower than three plain loads per step).
+#define RT_LDS_OR_GLOBAL(in_lds, lds_index, global_expr)          \
+    float4 r = rt_smem[(in_lds) ? (lds_index) : 0u];               \
+    if (!(in_lds)) r = (global_expr);                              \
+    return r;
+    // Wide node i: in LDS a node's eight 16-byte pieces may be stored XOR-swizzled by the node's index (RT_WNODE_SWIZZLE): every lane reads
+    // piece k of ITS node at the same time, and with plain 128-byte nodes those reads fall on two of the sixteen 16-byte cells of the
+    // 256-byte bank row (tools/gather_rate.hip); measured on the round-3 kernel, where LDS was idle: 1-2 % SLOWER (the address arithmetic).
     RT_DEV void wnode(uint32_t i, float4 (&n)[8]) const
     {
-        const bool in_lds = (head == 3u) & (8u * i < lds_f4);
+        const bool in_lds = i < n_w;
         const uint32_t k0 = in_lds ? 8u * i : 0u;
+        const uint32_t sw = RT_WNODE_SWIZZLE ? (in_lds ? (i & 7u) : 0u) : 0u;
 #pragma unroll
-        for (int k = 0; k < 8; k++) n[k] = rt_smem[k0 + k];
+        for (int k = 0; k < 8; k++) n[k] = rt_smem[k0 + ((uint32_t)k ^ sw)];
         if (!in_lds) {
 #pragma unroll
             for (int k = 0; k < 8; k++) n[k] = wnodes[8u * i + k];
         }
     }
-    // (the staged head is EITHER nodes | escape links OR the top block of the fixed-order walk's nodes OR that of the wide walk's)
-    // Element e of the fixed-order walk: from LDS when it is in the top block, else from global memory.  Written as an
-    // unconditional ds_read (of element 0 for the lanes that are past the block) plus a global load under a branch:
-    // a select between the two POINTERS makes the compiler emit flat loads, which take the texture path even for LDS
-    // and are waited for one by one (measured: the walk ran 12 % slower than with three loads per step).
+    // (the staged head is EITHER nodes | escape links OR the top block of the fixed-order walk's nodes OR the wide walk's image)
+    // Element e of the fixed-order walk: from LDS when it is in the top block, else from global memory.
     RT_DEV void pnode_pair(uint32_t e, float4 &n0, float4 &n1) const
     {
         const bool in_lds = (head == 2u) & (2u * e < lds_f4); // (the wide walk's fallback for rays with a non-finite 1/d comes here with head == 3)
@@ -200,16 +232,48 @@ struct SceneViewHybrid {
 #endif
     }
     RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
+#if RT_HOT_GLOBAL
+    RT_DEV float4 prim(uint32_t i) const { const bool in_lds = i < n_p_f4; RT_LDS_OR_GLOBAL(in_lds, o_p + i, prims[i]) }
+    // pieces 0 .. N-1 of primitive record `rec` (one decision for the record, not one per piece)
+    template <int N>
+    RT_DEV void prim_rec(uint32_t rec, float4 (&r)[N]) const
+    {
+        const bool in_lds = 4u * rec < n_p_f4;
+        const uint32_t k0 = in_lds ? o_p + 4u * rec : 0u;
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = rt_smem[k0 + (uint32_t)k];
+        if (!in_lds) {
+#pragma unroll
+            for (int k = 0; k < N; k++) r[k] = prims[4u * rec + (uint32_t)k];
+        }
+    }
+    RT_DEV float4 trin(uint32_t i) const { const bool in_lds = i < n_t_f4; RT_LDS_OR_GLOBAL(in_lds, o_t + i, tri_normals[i]) }
+    RT_DEV float4 mat(uint32_t i) const { const bool in_lds = i < n_m_f4; RT_LDS_OR_GLOBAL(in_lds, o_m + i, materials[i]) }
+    RT_DEV float4 rec(uint32_t src, uint32_t i) const
+    {
+        const ptrdiff_t ds = fb_spheres - prims, dp = fb_planes - prims; // all three live in one allocation
+        const bool in_lds = (src == SRC_BVH) & (i < n_p_f4);
+        RT_LDS_OR_GLOBAL(in_lds, o_p + i, prims[(src == SRC_FB_SPHERE ? ds : 0) + (src == SRC_FB_PLANE ? dp : 0) + (ptrdiff_t)i])
+    }
+#else // only wide nodes (or the other walks' heads) are staged: records and shading arrays come from global memory
     RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
+    template <int N>
+    RT_DEV void prim_rec(uint32_t rec, float4 (&r)[N]) const
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = prims[4u * rec + (uint32_t)k];
+    }
     RT_DEV float4 trin(uint32_t i) const { return tri_normals[i]; }
     RT_DEV float4 mat(uint32_t i) const { return materials[i]; }
-    RT_DEV float4 flat(uint32_t) const { return float4{0.0f, 0.0f, 0.0f, 0.0f}; } // (the flat traversal needs the whole image in LDS)
     RT_DEV float4 rec(uint32_t src, uint32_t i) const
     {
         const ptrdiff_t ds = fb_spheres - prims, dp = fb_planes - prims; // all three live in one allocation
         return prims[(src == SRC_FB_SPHERE ? ds : 0) + (src == SRC_FB_PLANE ? dp : 0) + (ptrdiff_t)i];
     }
+#endif
+    RT_DEV float4 flat(uint32_t) const { return float4{0.0f, 0.0f, 0.0f, 0.0f}; } // (the flat traversal needs the whole image in LDS)
     RT_DEV uint32_t esc(uint32_t i) const { return reinterpret_cast<const uint32_t *>(rt_smem + o_esc)[i]; }
+#undef RT_LDS_OR_GLOBAL
 };
 
 // ------------------------------------------------------------------ RNG (shader.wgsl:605-631)
@@ -1530,147 +1594,188 @@ RT_DEV void wstate_store(const WalkState &w, uint32_t *m, uint32_t stride)
 #ifndef RT_WIDE_HOLD
 #define RT_WIDE_HOLD 6 // triangles a lane wants to hold before it stops visiting nodes (a shadow ray: any; its first hit ends it)
 #endif
+// What a lane carries for ONE ray of the wide walk: the ray, its stack, and what it holds for the triangle loop — a 64-record WINDOW of
+// the (permuted) record array (the records of sibling nodes are neighbours there, so the leaves of several nodes usually share one
+// window) plus, once a node's triangles fall outside it, that node's group as overflow; then the lane stops visiting nodes and waits for
+// the wave's triangle loop.  A lane without a ray has w.cur == RT_END and holds nothing: it falls through both loops.
+struct WideRay {
+    V3 o, d, inv;
+    bool anyhit;
+    uint32_t octant;
+    WalkState w;
+    const uint32_t *ref_mem; // the slot's cold column with the record of an earlier call's best hit (read only on an equal t)
+    uint32_t win_base, ovf_base, ovf_tri;
+    unsigned long long tri_m;
+    RT_DEV void start(V3 o_, V3 d_, V3 inv_, bool anyhit_, const uint32_t *ref_mem_)
+    {
+        o = o_; d = d_; inv = inv_; anyhit = anyhit_; ref_mem = ref_mem_;
+        octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+        win_base = ovf_base = ovf_tri = 0u;
+        tri_m = 0ull;
+    }
+    RT_DEV void idle() // a lane without a ray
+    {
+        w.cur = RT_END; w.grp = 0u;
+        win_base = ovf_base = ovf_tri = 0u;
+        tri_m = 0ull;
+        anyhit = false; octant = 0u; ref_mem = nullptr;
+        o = d = inv = v3(0.0f, 0.0f, 0.0f);
+    }
+    RT_DEV bool holds() const { return tri_m != 0ull || ovf_tri != 0u; }
+    RT_DEV bool done() const { return w.cur == RT_END && !holds(); }
+    RT_DEV bool looking() const { return (w.cur != RT_END) & (ovf_tri == 0u) & ((uint32_t)__popcll(tri_m) < (anyhit ? 1u : (uint32_t)RT_WIDE_HOLD)); }
+};
+// equal t: the record the reference meets first wins (rare: coincident geometry)
+#define RT_WIDE_ACCEPT(t, rec)                                                                                   \
+    bool better = ((t) >= 0.0f) & ((t) < h.t);                                                                      \
+    if (((t) == h.t) & (h.t < RT_INFINITY)) {                                                                       \
+        if (h.ref == RT_REF_UNKNOWN) h.ref = *r.ref_mem;                                                            \
+        better = prim_rank_of(sc, r.octant, (rec)) < prim_rank_of(sc, r.octant, h.ref);                            \
+    }                                                                                                               \
+    h.t = better ? (t) : h.t;                                                                                       \
+    h.ref = better ? (rec) : h.ref;
+
+// One round's node visits: every lane visits nodes until it holds enough triangles (a shadow ray: any); the wave stops waiting once
+// fewer than `quorum` percent of the `n_started` lanes that hold a ray are still looking.
+template <class View>
+RT_DEV void wide_nodes(DBG_DECL const View &S, const DevScene &sc, WideRay &r, Hit &h, uint32_t quorum, uint32_t n_started, uint32_t &steps)
+{
+    const V3 o = r.o, d = r.d, inv = r.inv;
+    WalkState &w = r.w;
+    while (r.looking()) {
+        DBG_WAVE_TICK(10);
+        DBG_ADD(11, 1);
+        steps++;
+        float4 n[8];
+        S.wnode(w.cur, n);
+        // the eight .w words are the node's, not the slots': [0] first interior child's node index | interior-slot mask << 26,
+        // [1] first record of the node's leaf children, [2] / [3] which of the 32 records from there are triangles / planes,
+        // [4 + k] the records of slot k (0 unless it is a leaf) — so a hit turns into masks with a select and an OR
+        uint32_t hm = 0u, lm = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 n0 = n[2 * k], n1 = n[2 * k + 1];
+            const float ax = (n0.x - o.x) * inv.x, bx = (n1.x - o.x) * inv.x;
+            const float ay = (n0.y - o.y) * inv.y, by = (n1.y - o.y) * inv.y;
+            const float az = (n0.z - o.z) * inv.z, bz = (n1.z - o.z) * inv.z;
+            const float t_0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz)), 0.0f);
+            const float t_1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz)), RT_INFINITY);
+            const bool hit = !(t_0 > t_1);
+            hm |= hit ? (1u << k) : 0u;
+            lm |= hit ? as_u(n[4 + k].w) : 0u;
+        }
+        const uint32_t wa = as_u(n[0].w);
+        const uint32_t im = hm & (wa >> 26); // (an empty slot is in neither mask: its "hit" goes nowhere)
+        const uint32_t rec_base = as_u(n[1].w), tri32 = as_u(n[2].w), pl32 = as_u(n[3].w);
+        steps += (uint32_t)__popc(lm);
+        bool stop = false;
+        // planes and spheres (rare inside a mesh's tree): tested here and now, one at a time
+        uint32_t oth = lm & ~tri32;
+        while (oth != 0u) {
+            DBG_WAVE_TICK(15);
+            DBG_ADD(13, 1);
+            const uint32_t p = take_lowest(oth);
+            const uint32_t rec = rec_base + p;
+            float4 q[4];
+            S.template prim_rec<4>(rec, q);
+            const float t = ((pl32 >> p) & 1u) ? plane_t(o, d, v3(q[0].x, q[0].y, q[0].z), v3(q[1].x, q[1].y, q[1].z), v3(q[2].x, q[2].y, q[2].z), v3(q[3].x, q[3].y, q[3].z))
+                                               : sphere_t(o, d, v3(q[0].x, q[0].y, q[0].z), q[1].y);
+            RT_WIDE_ACCEPT(t, rec)
+            if (better & r.anyhit) { stop = true; oth = 0u; }
+        }
+        // triangles: into the window if they fall inside it, else this node's group is the overflow
+        const uint32_t ltri = lm & tri32;
+        if (ltri != 0u) {
+            const uint32_t shift = rec_base - r.win_base; // (wraps to a huge number when the group lies below the window)
+            if (r.tri_m == 0ull) { r.win_base = rec_base; r.tri_m = ltri; }
+            else if (shift <= 32u) r.tri_m |= (unsigned long long)ltri << shift;
+            else { r.ovf_base = rec_base; r.ovf_tri = ltri; }
+        }
+        // where next: the hit interior children become the pending group of a new level (the old one goes on the stack)
+        if (im != 0u) {
+            if ((w.grp & 15u) != 0u) wstack_push(w, w.grp);
+            w.grp = ((wa & 0x3ffffffu) << 4) | im; // interior children are consecutive: slot k is node (first child) + k
+        } else if ((w.grp & 15u) == 0u) {
+            w.grp = wstack_pop(w);
+        }
+        if ((w.grp & 15u) != 0u) {
+            w.cur = (w.grp >> 4) + (uint32_t)__builtin_ctz(w.grp);
+            w.grp &= w.grp - 1u;
+        } else {
+            w.cur = RT_END;
+        }
+        if (stop) { w.cur = RT_END; r.tri_m = 0ull; r.ovf_tri = 0u; }
+        if ((uint32_t)__popcll(__ballot(r.looking())) * 100u < n_started * quorum) break; // wave-uniform
+    }
+}
+
+// One round's triangle loop: the triangles of the window, two records in flight per trip.  Lanes hold very different numbers of them, so
+// the wave votes here too: once fewer than `quorum` percent of the lanes that entered still hold triangles the loop ends, and what a lane
+// has left simply stays in its window for the next round (nothing to save, nothing tested twice) — unless `all`: the wave is about to
+// stop, everything held is tested.  Afterwards the overflow group, if any, opens the next window.
+template <class View>
+RT_DEV void wide_tris(DBG_DECL const View &S, const DevScene &sc, WideRay &r, Hit &h, uint32_t quorum, bool all)
+{
+    const V3 o = r.o, d = r.d;
+    const uint32_t tri_started = (uint32_t)__popcll(__ballot(r.tri_m != 0ull));
+    while (r.tri_m != 0ull) {
+        DBG_WAVE_TICK(12);
+        DBG_ADD(13, 1);
+        const uint32_t rec_a = r.win_base + (uint32_t)__builtin_ctzll(r.tri_m);
+        r.tri_m &= r.tri_m - 1ull;
+        const bool two = r.tri_m != 0ull;
+        const uint32_t rec_b = two ? r.win_base + (uint32_t)__builtin_ctzll(r.tri_m) : rec_a;
+        r.tri_m &= r.tri_m - 1ull; // (0 & anything = 0)
+        float4 ra[3], rb[3];
+        S.template prim_rec<3>(rec_a, ra);
+        S.template prim_rec<3>(rec_b, rb);
+        float u, v;
+        bool stop = false;
+        {
+            const float t = triangle_t(o, d, v3(ra[0].x, ra[0].y, ra[0].z), v3(ra[1].x, ra[1].y, ra[1].z), v3(ra[2].x, ra[2].y, ra[2].z), u, v);
+            RT_WIDE_ACCEPT(t, rec_a)
+            stop = better & r.anyhit;
+        }
+        if (two & !stop) {
+            DBG_ADD(13, 1);
+            const float t = triangle_t(o, d, v3(rb[0].x, rb[0].y, rb[0].z), v3(rb[1].x, rb[1].y, rb[1].z), v3(rb[2].x, rb[2].y, rb[2].z), u, v);
+            RT_WIDE_ACCEPT(t, rec_b)
+            stop = better & r.anyhit;
+        }
+        if (stop) { r.w.cur = RT_END; r.tri_m = 0ull; r.ovf_tri = 0u; }
+        if (!all && (uint32_t)__popcll(__ballot(r.tri_m != 0ull)) * 100u < tri_started * quorum) break; // wave-uniform
+    }
+    if (r.ovf_tri != 0u && r.tri_m == 0ull) { r.win_base = r.ovf_base; r.tri_m = r.ovf_tri; r.ovf_tri = 0u; } // the overflow group opens the next window
+}
+#undef RT_WIDE_ACCEPT
+
+// One ray per lane, no refill (GEN's fused first trace, the probe): rounds of node visits and triangle tests until the ray is done, the
+// round budget is spent, or fewer than `stop_quorum` percent of the lanes that came in still hold a ray — then what is held is tested
+// and the lane returns with its stack in `w` (w.cur != RT_END) for the caller to park.
 template <class View>
 RT_DEV void trace_wide(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V3 inv, bool anyhit, uint32_t budget, uint32_t quorum, uint32_t stop_quorum,
                        WalkState &w, Hit &h, const uint32_t *ref_mem, uint32_t &work)
 {
-    const uint32_t octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    WideRay r;
+    r.start(o, d, inv, anyhit, ref_mem);
+    r.w = w;
     uint32_t steps = 0, rounds = 0;
-    const uint32_t started = (uint32_t)__popcll(__ballot(w.cur != RT_END));
-    // equal t: the record the reference meets first wins (rare: coincident geometry)
-#define RT_WIDE_ACCEPT(t, rec)                                                                                   \
-    bool better = ((t) >= 0.0f) & ((t) < h.t);                                                                      \
-    if (((t) == h.t) & (h.t < RT_INFINITY)) {                                                                       \
-        if (h.ref == RT_REF_UNKNOWN) h.ref = *ref_mem;                                                              \
-        better = prim_rank_of(sc, octant, (rec)) < prim_rank_of(sc, octant, h.ref);                                \
-    }                                                                                                               \
-    h.t = better ? (t) : h.t;                                                                                       \
-    h.ref = better ? (rec) : h.ref;
-    // What a lane holds for the triangle loop: a 64-record WINDOW of the (permuted) record array — the records of sibling nodes
-    // are neighbours there, so the leaves of several nodes usually share one window — plus, once a node's triangles fall outside
-    // it, that node's group as overflow; then the lane stops visiting and waits for the wave's triangle loop.
-    uint32_t win_base = 0u, ovf_base = 0u, ovf_tri = 0u;
-    unsigned long long tri_m = 0ull;
+    const uint32_t started = (uint32_t)__popcll(__ballot(r.w.cur != RT_END));
     bool stopping = false;
     for (;;) {
         DBG_WAVE_TICK(14);
-        // ---- nodes, until this lane holds enough triangles; the wave stops waiting once fewer than `quorum` percent of the
-        // lanes that started the round are still looking
-        if (!stopping) {
-            const uint32_t want = anyhit ? 1u : (uint32_t)RT_WIDE_HOLD;
-            const uint32_t n_started = (uint32_t)__popcll(__ballot(true));
-            while (w.cur != RT_END && ovf_tri == 0u && (uint32_t)__popcll(tri_m) < want) {
-                DBG_WAVE_TICK(10);
-                DBG_ADD(11, 1);
-                steps++;
-                float4 n[8];
-                S.wnode(w.cur, n);
-                // the eight .w words are the node's, not the slots': [0] first interior child's node index | interior-slot mask << 26,
-                // [1] first record of the node's leaf children, [2] / [3] which of the 32 records from there are triangles / planes,
-                // [4 + k] the records of slot k (0 unless it is a leaf) — so a hit turns into masks with a select and an OR
-                uint32_t hm = 0u, lm = 0u;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float4 n0 = n[2 * k], n1 = n[2 * k + 1];
-                    const float ax = (n0.x - o.x) * inv.x, bx = (n1.x - o.x) * inv.x;
-                    const float ay = (n0.y - o.y) * inv.y, by = (n1.y - o.y) * inv.y;
-                    const float az = (n0.z - o.z) * inv.z, bz = (n1.z - o.z) * inv.z;
-                    const float t_0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz)), 0.0f);
-                    const float t_1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz)), RT_INFINITY);
-                    const bool hit = !(t_0 > t_1);
-                    hm |= hit ? (1u << k) : 0u;
-                    lm |= hit ? as_u(n[4 + k].w) : 0u;
-                }
-                const uint32_t wa = as_u(n[0].w);
-                const uint32_t im = hm & (wa >> 26); // (an empty slot is in neither mask: its "hit" goes nowhere)
-                const uint32_t rec_base = as_u(n[1].w), tri32 = as_u(n[2].w), pl32 = as_u(n[3].w);
-                steps += (uint32_t)__popc(lm);
-                bool stop = false;
-                // planes and spheres (rare inside a mesh's tree): tested here and now, one at a time
-                uint32_t oth = lm & ~tri32;
-                while (oth != 0u) {
-                    DBG_WAVE_TICK(15);
-                    DBG_ADD(13, 1);
-                    const uint32_t p = take_lowest(oth);
-                    const uint32_t rec = rec_base + p;
-                    const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u);
-                    float t;
-                    if ((pl32 >> p) & 1u) {
-                        const float4 r2 = S.prim(4u * rec + 2u), r3 = S.prim(4u * rec + 3u);
-                        t = plane_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), v3(r3.x, r3.y, r3.z));
-                    } else {
-                        t = sphere_t(o, d, v3(r0.x, r0.y, r0.z), r1.y);
-                    }
-                    RT_WIDE_ACCEPT(t, rec)
-                    if (better & anyhit) { stop = true; oth = 0u; }
-                }
-                // triangles: into the window if they fall inside it, else this node's group is the overflow
-                const uint32_t ltri = lm & tri32;
-                if (ltri != 0u) {
-                    const uint32_t shift = rec_base - win_base; // (wraps to a huge number when the group lies below the window)
-                    if (tri_m == 0ull) { win_base = rec_base; tri_m = ltri; }
-                    else if (shift <= 32u) tri_m |= (unsigned long long)ltri << shift;
-                    else { ovf_base = rec_base; ovf_tri = ltri; }
-                }
-                // where next: the hit interior children become the pending group of a new level (the old one goes on the stack)
-                if (im != 0u) {
-                    if ((w.grp & 15u) != 0u) wstack_push(w, w.grp);
-                    w.grp = ((wa & 0x3ffffffu) << 4) | im; // interior children are consecutive: slot k is node (first child) + k
-                } else if ((w.grp & 15u) == 0u) {
-                    w.grp = wstack_pop(w);
-                }
-                if ((w.grp & 15u) != 0u) {
-                    w.cur = (w.grp >> 4) + (uint32_t)__builtin_ctz(w.grp);
-                    w.grp &= w.grp - 1u;
-                } else {
-                    w.cur = RT_END;
-                }
-                if (stop) { w.cur = RT_END; tri_m = 0ull; ovf_tri = 0u; }
-                if ((uint32_t)__popcll(__ballot((w.cur != RT_END) & (ovf_tri == 0u) & ((uint32_t)__popcll(tri_m) < want))) * 100u < n_started * quorum) break; // wave-uniform
-            }
-        }
-        // ---- the triangles of the window, two records in flight per trip.  Lanes hold very different numbers of them, so the wave
-        // votes here too: once fewer than `quorum` percent of the lanes that entered still hold triangles the loop ends, and what a
-        // lane has left simply stays in its window for the next round (nothing to save, nothing tested twice) — unless the wave
-        // is about to stop, when everything held is tested
-        const uint32_t tri_started = (uint32_t)__popcll(__ballot(tri_m != 0ull));
-        while (tri_m != 0ull) {
-            DBG_WAVE_TICK(12);
-            DBG_ADD(13, 1);
-            const uint32_t rec_a = win_base + (uint32_t)__builtin_ctzll(tri_m);
-            tri_m &= tri_m - 1ull;
-            const bool two = tri_m != 0ull;
-            const uint32_t rec_b = two ? win_base + (uint32_t)__builtin_ctzll(tri_m) : rec_a;
-            tri_m &= tri_m - 1ull; // (0 & anything = 0)
-            const float4 a0 = S.prim(4u * rec_a), a1 = S.prim(4u * rec_a + 1u), a2 = S.prim(4u * rec_a + 2u);
-            const float4 b0 = S.prim(4u * rec_b), b1 = S.prim(4u * rec_b + 1u), b2 = S.prim(4u * rec_b + 2u);
-            float u, v;
-            bool stop = false;
-            {
-                const float t = triangle_t(o, d, v3(a0.x, a0.y, a0.z), v3(a1.x, a1.y, a1.z), v3(a2.x, a2.y, a2.z), u, v);
-                RT_WIDE_ACCEPT(t, rec_a)
-                stop = better & anyhit;
-            }
-            if (two & !stop) {
-                DBG_ADD(13, 1);
-                const float t = triangle_t(o, d, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z), v3(b2.x, b2.y, b2.z), u, v);
-                RT_WIDE_ACCEPT(t, rec_b)
-                stop = better & anyhit;
-            }
-            if (stop) { w.cur = RT_END; tri_m = 0ull; ovf_tri = 0u; }
-            if (!stopping && (uint32_t)__popcll(__ballot(tri_m != 0ull)) * 100u < tri_started * quorum) break; // wave-uniform
-        }
-        if (ovf_tri != 0u && tri_m == 0ull) { win_base = ovf_base; tri_m = ovf_tri; ovf_tri = 0u; } // the overflow group opens the next window
+        if (!stopping) wide_nodes(DBG_ARG S, sc, r, h, quorum, (uint32_t)__popcll(__ballot(true)), steps);
+        wide_tris(DBG_ARG S, sc, r, h, quorum, stopping);
         // ---- go on?  A lane leaves when it is done, or when the wave stops and it holds nothing (what it holds is tested first)
         if (stopping) {
-            if (tri_m == 0ull) break;
+            if (r.tri_m == 0ull) break;
             continue;
         }
         rounds++; // (wave-uniform: every lane still here has run the same number of rounds)
-        stopping = rounds >= budget || (uint32_t)__popcll(__ballot((w.cur != RT_END) | (tri_m != 0ull))) * 100u < started * stop_quorum;
-        if (tri_m == 0ull && (stopping || w.cur == RT_END)) break;
+        stopping = rounds >= budget || (uint32_t)__popcll(__ballot((r.w.cur != RT_END) | (r.tri_m != 0ull))) * 100u < started * stop_quorum;
+        if (r.tri_m == 0ull && (stopping || r.w.cur == RT_END)) break;
     }
-#undef RT_WIDE_ACCEPT
+    w = r.w;
     work += steps;
 }
 

@@ -91,13 +91,33 @@ enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_FINISH 
 #define RT_FLAT_PRIM_STAGE 0 // measured: 28.2 ms per 64 spp at its best quorum (40-50) against 28.0 ms without it at quorum 20; the sixth stage costs the census 1 %
 #endif
 
-template <uint32_t POOL, int TRAV>
+// RT_HOT_GLOBAL (experiment, default 0 in rt_device.h): the walk kernels (hybrid scene view, SV 2) keep only the TAG column of the hot state in
+// LDS; the other ten hot columns follow the cold ones in the wave's global arena, and what a ray gathers per lane — wide nodes, primitive
+// records, normals, materials — takes the 120 KB of LDS they held (rsrt_api.hip, wide_image).  The idea: the vector memory path is busy
+// 93-97 % of the cycles in these kernels, and a wave's state column is 768 contiguous bytes while the scene reads are per-lane gathers.
+// Measured: NOT faster (suzanne +9 %, 15 k-triangle scene +-0): a column read by 64 scattered slots still costs the path ~30 tag
+// lookups (it coalesces per quad of lanes, not per line), and every stage now starts with an L2 round trip.
+// RT_WIDE_REFILL: the wide walk's TRACE stage takes a LIST of waiting rays longer than the wave — a lane whose ray is done takes the next one
+// between two rounds — and the scheduler lets such lists build up (see "2. which stage" in the kernel).  Why: rays need 3-25 node visits,
+// and with one ray per lane and stage call the node and triangle loops ran at 54-61 % of the lanes (profiles/r03_wide_walk.txt).
+#ifndef RT_WIDE_REFILL
+#define RT_WIDE_REFILL 0
+#endif
+#ifndef RT_SCALAR_WAVE
+#define RT_SCALAR_WAVE 0 // 1: every pool kernel is told that its wave index is wave-uniform (scalar LDS / arena bases), and SHADE writes through an opaque copy of the slot index
+#endif
+#ifndef RT_REFILL_LIST
+#define RT_REFILL_LIST 128u // entries of the compaction list of the kernels that refill (the others: 64, one per lane)
+#endif
+__host__ __device__ constexpr uint32_t pool_list_dwords(int trav) { return (RT_WIDE_REFILL && trav == 4) ? (uint32_t)RT_REFILL_LIST : 64u; }
+template <uint32_t POOL, int TRAV, bool HOTG>
 struct PoolLayout {
     static constexpr uint32_t kSlotsPerLane = (POOL + 63u) / 64u;
-    static constexpr uint32_t kHotDwords = H_COUNT * POOL;
-    static constexpr uint32_t kListDwords = 64u;
+    static constexpr uint32_t kHotDwords = (HOTG ? 1u : (uint32_t)H_COUNT) * POOL; // in LDS: every hot column, or the tag column alone
+    static constexpr uint32_t kListDwords = pool_list_dwords(TRAV);
     static constexpr uint32_t kWaveLdsDwords = kHotDwords + kListDwords;
-    static constexpr uint32_t kWaveColdDwords = pool_cold_columns(TRAV) * POOL;
+    static constexpr uint32_t kColdColumns = pool_cold_columns(TRAV);
+    static constexpr uint32_t kWaveColdDwords = (kColdColumns + (HOTG ? (uint32_t)H_CT : 0u)) * POOL; // (H_CT = the number of hot columns before the tag)
 };
 
 RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE, MISS, SHADE, FINISH, PRIM; IDLE -> none
@@ -154,7 +174,8 @@ template <> struct PoolView<2> { typedef SceneViewHybrid type; static __device__
 template <int SV, uint32_t BLOCK, uint32_t POOL, int TRAV>
 __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
 {
-    typedef PoolLayout<POOL, TRAV> L;
+    constexpr bool kHotG = RT_HOT_GLOBAL != 0 && SV == 2; // hot columns (all but the tag) in the global arena
+    typedef PoolLayout<POOL, TRAV, kHotG> L;
     constexpr bool kBounceInCt = pool_cold_columns(TRAV) == (uint32_t)C_COUNT_FLAT; // no C_BOUNCE / C_REF column
     // Flat traversal: a ray finishes in one TRACE call — or is cut short by the triangle-loop vote with its best t parked where the
     // result would go — so "best t so far" is INFINITY at every fresh start and the H_T cell is
@@ -165,6 +186,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     constexpr uint32_t kTCell = kRngHot ? (uint32_t)H_SX : (uint32_t)H_T; // where the extension ray's t waits for SHADE / MISS
     constexpr bool kFlatVote = RT_FLAT_VOTE && kRngHot && kBounceInCt; // a TRACE call may return a flat traversal unfinished
     constexpr bool kPackedMiss = RT_ENV_PACKED != 0 && TRAV == 2; // MISS reads an escaping ray's pmf from the texels' alpha (rt_device.h)
+    constexpr bool kRefill = RT_WIDE_REFILL != 0 && TRAV == 4; // TRACE refills its lanes from a list longer than the wave
     constexpr bool kGenTrace = RT_GEN_TRACE != 0 && TRAV >= 2; // GEN traces the camera ray it has built (the near-first tree walks, kept for RSRT_FLAG_PRUNE, would spill)
     constexpr uint32_t ST_COUNT = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)ST_MAX : (uint32_t)ST_PRIM;
     constexpr uint32_t kTagCut = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)TAG_PRIM : (uint32_t)TAG_TRACE;
@@ -172,21 +194,31 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     if (SV != 0) stage_scene_lds(sc);
     const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
-    const uint32_t wave = threadIdx.x / RT_WAVE;
+    // (readfirstlane: the compiler cannot know that threadIdx.x / 64 is wave-uniform; told so, the wave's LDS and arena bases live in scalar
+    // registers and a column access is base + 32-bit lane offset instead of a 64-bit address per lane)
+    // (RT_SCALAR_WAVE 0: only the walk kernels — the flat kernel, which already holds its cull boxes in scalar registers, runs out of them)
+    constexpr bool kScalarWave = SV == 2 || RT_SCALAR_WAVE != 0;
+    const uint32_t wave = kScalarWave ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / RT_WAVE)) : threadIdx.x / RT_WAVE;
     uint32_t *const lds32 = reinterpret_cast<uint32_t *>(rt_smem + sc.lds_float4s);
-    uint32_t *const W = lds32 + wave * L::kWaveLdsDwords; // this wave's hot columns
+    uint32_t *const W = lds32 + wave * L::kWaveLdsDwords; // this wave's hot columns (kHotG: its tag column)
+    uint32_t *const WCT = W + (kHotG ? 0u : (uint32_t)H_CT * POOL); // the tag column: always LDS (the census reads all of it every trip)
     uint32_t *const list = W + L::kHotDwords;
     uint32_t *const G = P.cold_state + (size_t)(blockIdx.x * (BLOCK / RT_WAVE) + wave) * L::kWaveColdDwords; // cold columns
+    uint32_t *const GH = G + L::kColdColumns * POOL; // kHotG: the hot columns H_OX .. H_T, behind the cold ones
     const bool prune = (P.flags & RSRT_FLAG_PRUNE) != 0;
     const bool anyhit_shadow = !(P.flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
     const uint32_t tile_px = P.tile_w * P.tile_h;
 
-#define HOT(f, slot) W[(f) * POOL + (slot)]
-#define HOTF(f, slot) as_f(W[(f) * POOL + (slot)])
-#define SETH(f, slot, val) W[(f) * POOL + (slot)] = as_u(val)
-#define TAG_OF(slot) (W[H_CT * POOL + (slot)] & 7u)
-#define SET_TAG(slot, tag) W[H_CT * POOL + (slot)] = (uint32_t)(tag)              /* no flags, cursor := root (0) */
-#define SET_CT(slot, payload, flags, tag) W[H_CT * POOL + (slot)] = ((payload) << CT_SHIFT) | (flags) | (uint32_t)(tag)
+    // (kHotG is a constant: each of these is ONE load or store, from the arena or from LDS — never a select between two pointers,
+    // which would compile to flat loads)
+#define HOT(f, slot) (kHotG ? GH[(f) * POOL + (slot)] : W[(f) * POOL + (slot)])           /* a hot column other than the tag, as u32 */
+#define HOTF(f, slot) as_f(HOT(f, slot))
+#define SETHU(f, slot, val) do { if (kHotG) GH[(f) * POOL + (slot)] = (val); else W[(f) * POOL + (slot)] = (val); } while (0)
+#define SETH(f, slot, val) SETHU(f, slot, as_u(val))
+#define CT_OF(slot) WCT[(slot)]
+#define TAG_OF(slot) (WCT[(slot)] & 7u)
+#define SET_TAG(slot, tag) WCT[(slot)] = (uint32_t)(tag)              /* no flags, cursor := root (0) */
+#define SET_CT(slot, payload, flags, tag) WCT[(slot)] = ((payload) << CT_SHIFT) | (flags) | (uint32_t)(tag)
 #define COLD(f, slot) G[(f) * POOL + (slot)]
 #define COLDF(f, slot) as_f(G[(f) * POOL + (slot)])
 #define SETC(f, slot, val) G[(f) * POOL + (slot)] = as_u(val)
@@ -215,27 +247,10 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
 #else
 #define SHADE_STAMP(i) do { } while (0)
 #endif
-    // One ray of `slot` (tag / flags word `ct`) from o along d, traced or resumed, and what the slot is left as: TRACE's body, as a
-    // lambda because GEN runs it too (RT_GEN_TRACE: a new path's camera ray is traced by the lanes that have just built it).
-    auto trace_slot = [&](const uint32_t slot, const uint32_t ct, const V3 o, const V3 d, const bool coherent) __attribute__((always_inline)) {
+    // What a slot is left as once its ray has been traced as far as this call goes (cur == RT_END: to the end): the end of TRACE's body.
+    auto ray_end = [&](const uint32_t slot, const uint32_t ct, const Hit &h, const uint32_t cur, const float t_in, const unsigned long long flat_rem) __attribute__((always_inline)) {
         const bool shadow = (ct & F_SHADOW) != 0u;
-        // resume (or start: cur = root, best = INFINITY) the traversal
-        Hit h;
-        uint32_t cur = kBounceInCt ? (kFlatVote ? (ct >> (CT_SHIFT + 24u)) : 0u) : (ct >> CT_SHIFT); // (flat: the bits carry the bounce count)
         const uint32_t bounce_bits = kBounceInCt ? ((ct >> CT_SHIFT) & RT_FLAT_BOUNCE_BITS) : 0u;
-        h.src = SRC_BVH;
-        h.t = kRngHot ? RT_INFINITY : HOTF(H_T, slot); h.u = h.v = 0.0f;
-        unsigned long long flat_rem = 0ull;
-        if (kFlatVote && cur != 0u) { // cut short by the vote of an earlier call: the untested triangles, the best hit so far
-            flat_rem = ((unsigned long long)COLD(C_REM_HI, slot) << 32) | COLD(C_REM_LO, slot);
-            if (!shadow) h.t = HOTF(kTCell, slot);
-        }
-        // the record of an earlier call's best hit stays in the cold column unless beaten; the fixed-order walk, where
-        // an equal t can still replace it, fetches it from there if (and only if) such a tie comes up
-        h.ref = (TRAV >= 3 && !shadow) ? RT_REF_UNKNOWN : ((kFlatVote && cur != 0u) ? ((ct >> CT_SHIFT) & 63u) : 0u);
-        const float t_in = h.t;
-        trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, TRAV == 2 ? (kFlatVote ? P.flat_quorum : 0u) : P.descend_quorum,
-                             cur, h, &COLD(C_REF, slot), n_work, flat_rem, TRAV == 4 ? &G[C_WIDE_STATE * POOL + slot] : nullptr, POOL, P.stop_quorum, coherent);
         const bool found = TRAV >= 3 ? (h.ref != RT_REF_UNKNOWN) : (h.t < t_in); // this call found a closer (or earlier-ranked) hit
         // (a shadow ray that is cut short with a hit in hand is done whatever the flags say: only did_hit is read)
         const bool done = cur == RT_END || (kFlatVote && shadow && h.t < RT_INFINITY);
@@ -261,6 +276,28 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             SET_CT(slot, (TRAV == 2 ? h.ref : 0u) | bounce_bits, ct & (F_NEE | F_OCCLUDED), h.did_hit() ? TAG_SHADE : TAG_MISS);
         }
     };
+    // One ray of `slot` (tag / flags word `ct`) from o along d, traced or resumed, and what the slot is left as: TRACE's body, as a
+    // lambda because GEN runs it too (RT_GEN_TRACE: a new path's camera ray is traced by the lanes that have just built it).
+    auto trace_slot = [&](const uint32_t slot, const uint32_t ct, const V3 o, const V3 d, const bool coherent) __attribute__((always_inline)) {
+        const bool shadow = (ct & F_SHADOW) != 0u;
+        // resume (or start: cur = root, best = INFINITY) the traversal
+        Hit h;
+        uint32_t cur = kBounceInCt ? (kFlatVote ? (ct >> (CT_SHIFT + 24u)) : 0u) : (ct >> CT_SHIFT); // (flat: the bits carry the bounce count)
+        h.src = SRC_BVH;
+        h.t = kRngHot ? RT_INFINITY : HOTF(H_T, slot); h.u = h.v = 0.0f;
+        unsigned long long flat_rem = 0ull;
+        if (kFlatVote && cur != 0u) { // cut short by the vote of an earlier call: the untested triangles, the best hit so far
+            flat_rem = ((unsigned long long)COLD(C_REM_HI, slot) << 32) | COLD(C_REM_LO, slot);
+            if (!shadow) h.t = HOTF(kTCell, slot);
+        }
+        // the record of an earlier call's best hit stays in the cold column unless beaten; the fixed-order walk, where
+        // an equal t can still replace it, fetches it from there if (and only if) such a tie comes up
+        h.ref = (TRAV >= 3 && !shadow) ? RT_REF_UNKNOWN : ((kFlatVote && cur != 0u) ? ((ct >> CT_SHIFT) & 63u) : 0u);
+        const float t_in = h.t;
+        trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, TRAV == 2 ? (kFlatVote ? P.flat_quorum : 0u) : P.descend_quorum,
+                             cur, h, &COLD(C_REF, slot), n_work, flat_rem, TRAV == 4 ? &G[C_WIDE_STATE * POOL + slot] : nullptr, POOL, P.stop_quorum, coherent);
+        ray_end(slot, ct, h, cur, t_in, flat_rem);
+    };
     for (;;) {
         DBG_STAMP(21); // previous stage's tail is charged below; this resets the clock for the census
         // ---------------- 1. census of the stage tags (each lane looks at its kSlotsPerLane slots)
@@ -272,10 +309,16 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             for (uint32_t s = 0; s < ST_COUNT; s++) count[s] += (uint32_t)__popcll(__ballot(st == s));
         }
         if (exhausted) count[ST_GEN] = 0;
-        // ---------------- 2. fullest stage (ties: the later stage, which drains paths)
+        // ---------------- 2. which stage: the fullest (ties: the later stage, which drains paths)
         uint32_t best = ST_COUNT, best_n = 0;
         for (uint32_t s = 0; s < ST_COUNT; s++)
-            if (count[s] >= best_n && count[s] > 0) { best = s; best_n = count[s]; }
+            if (count[s] >= best_n && count[s] > 0 && !(kRefill && s == ST_TRACE)) { best = s; best_n = count[s]; }
+        if (kRefill) {
+            // ... but a TRACE that refills its lanes wants a LONG list: the other stages run while one of them can fill the wave, TRACE once
+            // P.refill_min rays wait for it, and short of both whichever is nearer its mark
+            const uint32_t tn = count[ST_TRACE];
+            if (tn > 0u && (best == ST_COUNT || (best_n < 64u && (tn >= P.refill_min || tn * 64u > best_n * P.refill_min)))) { best = ST_TRACE; best_n = tn; }
+        }
         if (best == ST_COUNT) break; // nothing left anywhere
         // ---------------- 3. compaction: dense list of the chosen stage's slots
         uint32_t base = 0;
@@ -283,7 +326,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             const bool mine = stage_of_tag(tags[k]) == best;
             const unsigned long long m = __ballot(mine);
             const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (mine && pos < 64u) list[pos] = lane + 64u * k;
+            if (mine && pos < L::kListDwords) list[pos] = lane + 64u * k;
             base += (uint32_t)__popcll(m);
         }
         RT_WAVE_HANDOVER(); // list[] is read by other lanes than wrote it
@@ -292,7 +335,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         const uint32_t slot = on ? list[lane] : 0u;
         const uint32_t dbg_stage = best == ST_PRIM ? (uint32_t)ST_TRACE : best; // (the diagnostic counters file PRIM under TRACE)
         (void)dbg_stage;
-        if (lane == 0) { DBG_ADD(dbg_stage, 1); DBG_ADD(5 + dbg_stage, n_run); }
+        if (lane == 0) { DBG_ADD(dbg_stage, 1); DBG_ADD(5 + dbg_stage, (kRefill && best == ST_TRACE) ? min(best_n, L::kListDwords) : n_run); }
         DBG_STAMP(22); // census + compaction
 
         if (best == ST_GEN) {
@@ -329,7 +372,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                         start_path(P, px, py, P.sample_begin + srel, ps);
                         SETH(H_OX, slot, ps.o.x); SETH(H_OY, slot, ps.o.y); SETH(H_OZ, slot, ps.o.z);
                         SETH(H_EX, slot, ps.d.x); SETH(H_EY, slot, ps.d.y); SETH(H_EZ, slot, ps.d.z);
-                        if (kRngHot) HOT(H_T, slot) = ps.rng; else SETH(H_T, slot, RT_INFINITY);
+                        if (kRngHot) SETHU(H_T, slot, ps.rng); else SETH(H_T, slot, RT_INFINITY);
                         SETC(C_TX, slot, 1.0f); SETC(C_TY, slot, 1.0f); SETC(C_TZ, slot, 1.0f);
                         SETC(C_LX, slot, 0.0f); SETC(C_LY, slot, 0.0f); SETC(C_LZ, slot, 0.0f);
                         SETC(C_LASTPDF, slot, 1.0f);
@@ -353,11 +396,96 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
                     if (lane + 64u * k < POOL && TAG_OF(lane + 64u * k) == TAG_FREE) SET_TAG(lane + 64u * k, TAG_IDLE);
             }
+        } else if (kRefill && best == ST_TRACE) {
+            // ---------------- TRACE with refill (wide walk): the list holds up to kListDwords waiting rays; lanes take them in list order, and a
+            // lane whose ray is done takes the next one between two rounds.  Once the list is used up and fewer than P.stop_quorum percent of
+            // the lanes still hold a ray, what is held is tested and the unfinished rays park their stacks (cold columns) for the next TRACE.
+            // A ray's arithmetic is what it is in any other schedule: which lane runs it, and beside whom, changes nothing.
+            if constexpr (kRefill) {
+                const uint32_t n_list = min(best_n, L::kListDwords), n_ref = min(n_list, 64u);
+                uint32_t next = 0u, steps = 0u;
+                bool have = false;   // this lane holds a ray of the wide walk
+                bool axial = false;  // this lane holds a ray with a non-finite 1/d: it waits for the fixed-order walk behind the loop
+                uint32_t my_slot = 0u, my_ct = 0u;
+                float my_t_in = 0.0f;
+                WideRay r;
+                Hit h;
+                r.idle();
+                r.w.s0 = r.w.s1 = r.w.s2 = r.w.s3 = r.w.s4 = r.w.s5 = r.w.s6 = r.w.s7 = 0u;
+                h.t = RT_INFINITY; h.ref = 0u; h.src = SRC_BVH; h.u = h.v = 0.0f;
+                for (;;) {
+                    // free lanes take the next slots of the list
+                    if (next < n_list) {
+                        const unsigned long long want = __ballot(!have & !axial);
+                        const uint32_t idx = next + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                        if (!have && !axial && idx < n_list) {
+                            const uint32_t s = list[idx];
+                            const uint32_t ct = CT_OF(s);
+                            const bool shadow = (ct & F_SHADOW) != 0u;
+                            const uint32_t dcol = shadow ? (uint32_t)H_SX : (uint32_t)H_EX;
+                            const V3 o = v3(HOTF(H_OX, s), HOTF(H_OY, s), HOTF(H_OZ, s));
+                            const V3 d = v3(HOTF(dcol, s), HOTF(dcol + 1u, s), HOTF(dcol + 2u, s));
+                            h.t = HOTF(H_T, s);
+                            h.ref = shadow ? 0u : RT_REF_UNKNOWN; // (an earlier call's best record stays in its cold column unless beaten, see trace_slot)
+                            my_slot = s; my_ct = ct; my_t_in = h.t;
+                            const V3 inv = rt_rcp3(d);
+                            const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f; // (as in trace_dispatch)
+                            if (finite == 0.0f) {
+                                r.start(o, d, inv, shadow && anyhit_shadow, &COLD(C_REF, s));
+                                if ((ct >> CT_SHIFT) != 0u) { // parked by an earlier call
+                                    wstate_load(r.w, &G[C_WIDE_STATE * POOL + s], POOL);
+                                } else {
+                                    r.w.cur = 0u; r.w.grp = 0u;
+                                    r.w.s0 = r.w.s1 = r.w.s2 = r.w.s3 = r.w.s4 = r.w.s5 = r.w.s6 = r.w.s7 = 0u;
+                                }
+                                have = true;
+                            } else { // a non-finite 1/d (axis-parallel rays: next to none): the fixed-order walk, behind the loop; the lane sits out
+                                axial = true;
+                            }
+                        }
+                        next = min(n_list, next + (uint32_t)__popcll(want));
+                    }
+                    const uint32_t n_have = (uint32_t)__popcll(__ballot(have));
+                    if (n_have == 0u) { if (next >= n_list) break; continue; }
+                    DBG_WAVE_TICK(14);
+                    wide_nodes(DBG_ARG S, sc, r, h, P.descend_quorum, n_have, steps);
+                    wide_tris(DBG_ARG S, sc, r, h, P.descend_quorum, false);
+                    if (have && r.done()) { // this ray is through: the lane is free for the next
+                        ray_end(my_slot, my_ct, h, RT_END, my_t_in, 0ull);
+                        have = false;
+                        r.idle();
+                    }
+                    if (next >= n_list) {
+                        const uint32_t n_act = (uint32_t)__popcll(__ballot(have));
+                        if (n_act == 0u) break;
+                        if (n_act * 100u < n_ref * P.stop_quorum) { // the wave stops here
+                            while (__ballot(r.holds()) != 0ull) wide_tris(DBG_ARG S, sc, r, h, P.descend_quorum, true);
+                            if (have) {
+                                if (r.w.cur != RT_END) wstate_store(r.w, &G[C_WIDE_STATE * POOL + my_slot], POOL);
+                                ray_end(my_slot, my_ct, h, r.w.cur == RT_END ? RT_END : 1u, my_t_in, 0ull);
+                            }
+                            break;
+                        }
+                    }
+                }
+                n_work += steps;
+                if (axial) { // (its slot's columns are as they were: read again, walk to the end)
+                    const bool shadow = (my_ct & F_SHADOW) != 0u;
+                    const uint32_t dcol = shadow ? (uint32_t)H_SX : (uint32_t)H_EX;
+                    const V3 o = v3(HOTF(H_OX, my_slot), HOTF(H_OY, my_slot), HOTF(H_OZ, my_slot));
+                    const V3 d = v3(HOTF(dcol, my_slot), HOTF(dcol + 1u, my_slot), HOTF(dcol + 2u, my_slot));
+                    Hit ha;
+                    ha.t = HOTF(H_T, my_slot); ha.ref = shadow ? 0u : RT_REF_UNKNOWN; ha.src = SRC_BVH; ha.u = ha.v = 0.0f;
+                    uint32_t cur = my_ct >> CT_SHIFT;
+                    trace_preorder(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, 0xffffffffu, 0u, cur, ha, &COLD(C_REF, my_slot), n_work);
+                    ray_end(my_slot, my_ct, ha, RT_END, ha.t, 0ull);
+                }
+            }
         } else if (best == ST_TRACE || best == ST_PRIM) {
             // ---------------- TRACE: one ray of the slot from its vertex O — the shadow ray (direction S, any
             // hit) while one is pending, else the extension ray (direction E, closest hit): cast_ray_bvh
             if (on) {
-                const uint32_t ct = HOT(H_CT, slot);
+                const uint32_t ct = CT_OF(slot);
                 const uint32_t dcol = (ct & F_SHADOW) ? (uint32_t)H_SX : (uint32_t)H_EX;
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
                 const V3 d = v3(HOTF(dcol, slot), HOTF(dcol + 1u, slot), HOTF(dcol + 2u, slot));
@@ -366,7 +494,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         } else if (best == ST_MISS) {
             // ---------------- MISS: brute-force fallback of cast_ray (shader.wgsl:583-598), then escape
             if (on) {
-                const uint32_t ct = HOT(H_CT, slot);
+                const uint32_t ct = CT_OF(slot);
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
                 const V3 d = v3(HOTF(H_EX, slot), HOTF(H_EY, slot), HOTF(H_EZ, slot));
                 // Memory first, as in SHADE: what the escape needs — four texels, the alias entry of the texel under the ray, the
@@ -418,7 +546,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         } else if (best == ST_SHADE) {
             // ---------------- SHADE: one whole iteration of trace_ray's loop body at a hit (shader.wgsl:1233-1299)
             if (on) {
-                const uint32_t ct = HOT(H_CT, slot);
+                const uint32_t ct = CT_OF(slot);
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
                 const V3 d = v3(HOTF(H_EX, slot), HOTF(H_EY, slot), HOTF(H_EZ, slot));
                 Hit h;
@@ -505,12 +633,18 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     store_sample(P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u, Lr);
                     SET_TAG(slot, TAG_FREE);
                 } else {
+                    // (kHotG: the columns read at the top of the stage are written here; an opaque copy of the slot index keeps the compiler
+                    // from carrying their 64-bit addresses through the whole stage — they spilled)
+                    const uint32_t slot_r = slot;
+                    uint32_t slot_w = slot_r;
+                    if (kHotG || RT_SCALAR_WAVE != 0) asm volatile("" : "+v"(slot_w));
+#define slot slot_w
                     SETC(C_LX, slot, Lr.x); SETC(C_LY, slot, Lr.y); SETC(C_LZ, slot, Lr.z);
                     if (nee_counts) { SETC(C_NEEX, slot, nee.x); SETC(C_NEEY, slot, nee.y); SETC(C_NEEZ, slot, nee.z); }
                     if (!finished) {
                         SETC(C_LASTPDF, slot, bs.pdf);
                         SETC(C_TX, slot, T.x); SETC(C_TY, slot, T.y); SETC(C_TZ, slot, T.z);
-                        if (kRngHot) HOT(H_T, slot) = rng; else COLD(C_RNG, slot) = rng;
+                        if (kRngHot) SETHU(H_T, slot, rng); else COLD(C_RNG, slot) = rng;
                         if (!kBounceInCt) COLD(C_BOUNCE, slot) = bounce;
                         SETH(H_EX, slot, bs.dir.x); SETH(H_EY, slot, bs.dir.y); SETH(H_EZ, slot, bs.dir.z);
                     }
@@ -519,12 +653,13 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     if (!kRngHot) SETH(H_T, slot, RT_INFINITY);
                     SET_CT(slot, kBounceInCt ? (bounce << RT_FLAT_BOUNCE_SHIFT) : 0u,
                            (want_shadow ? (uint32_t)F_SHADOW : 0u) | (finished ? 0u : (uint32_t)F_EXT) | (nee_counts ? (uint32_t)F_NEE : 0u), TAG_TRACE);
+#undef slot
                 }
             }
         } else {
             // ---------------- FINISH: the path ended at its last vertex; its shadow ray is back
             if (on) {
-                const uint32_t ct = HOT(H_CT, slot);
+                const uint32_t ct = CT_OF(slot);
                 V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
                 if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + v3(COLDF(C_NEEX, slot), COLDF(C_NEEY, slot), COLDF(C_NEEZ, slot));
                 store_sample(P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u, Lr);
@@ -536,7 +671,9 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     }
 #undef HOT
 #undef HOTF
+#undef SETHU
 #undef SETH
+#undef CT_OF
 #undef TAG_OF
 #undef SET_TAG
 #undef SET_CT
