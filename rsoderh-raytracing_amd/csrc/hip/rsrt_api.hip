@@ -551,7 +551,9 @@ struct rsrt_context {
     // 256-thread form of the kernel with one workgroup per CU, so that up to four calls are resident side by side and one call's
     // ~0.5 ms of pipeline fill and drain is covered by its neighbours' steady state (a call alone on the GPU keeps the full grid:
     // its latency is what counts then).
-    Lane lanes[4];
+    Lane lanes[8];
+    uint32_t n_lanes = 4;   // lanes in use (RSRT_PIPE_LANES: 2 .. 8)
+    uint32_t pipe_div = 1;  // a pipelined small job's grid is a CU's worth of workgroups / pipe_div (RSRT_PIPE_DIV: with 8 lanes and 2, each of eight resident jobs has half as many waves that each run twice as long)
     uint32_t next_small_lane = 1;
     bool overlap = true;
     uint64_t small_paths = 4ull << 20;
@@ -952,7 +954,7 @@ int select_traversal(const rsrt_context *ctx, const DevScene &sc, uint32_t max_b
 
 // One pass of rsrt_render: the path-tracing kernel over P.sample_count samples, then the ordered resolve.
 rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context::PassEvents &pe, const void *kfn, uint32_t block, int bpc,
-                         size_t smem, size_t per_sample, uint32_t max_bounces, hipStream_t caller_stream, rsrt_context::Lane &lane)
+                         size_t smem, size_t per_sample, uint32_t max_bounces, hipStream_t caller_stream, rsrt_context::Lane &lane, uint32_t grid_div = 1)
 {
     const uint32_t tile_px = P.tile_w * P.tile_h;
     // the path-tracing kernel: on the lane's stream (behind the resolve that last read this lane's sample buffer: same stream)
@@ -964,7 +966,7 @@ rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context:
         // partitioned frame — so that every resident wave still gets >= ~32 chunks and the tail,
         // where waves run out of work at different times, stays a few percent.
         {
-            const uint64_t waves = (uint64_t)ctx->cus * bpc * (block / RT_WAVE);
+            const uint64_t waves = (uint64_t)ctx->cus * bpc * (block / RT_WAVE) / grid_div;
             const uint64_t want_chunks = (uint64_t)ctx->chunks_per_wave * waves;
             const uint64_t total_tile_samples = (uint64_t)P.n_owned_tiles * P.sample_count;
             uint64_t spc = total_tile_samples / std::max<uint64_t>(want_chunks, 1);
@@ -985,7 +987,7 @@ rsrt_status enqueue_pass(rsrt_context *ctx, RenderParams &P, const rsrt_context:
         HIP_TRY(ctx, hipMemsetAsync(lane.work_counter, 0, sizeof(unsigned int), stream));
         const uint32_t waves_wanted = (uint32_t)std::min<uint64_t>(n_chunks, 0x7fffffffull);
         const uint32_t wpb = block / RT_WAVE;
-        uint32_t grid = std::min<uint32_t>((waves_wanted + wpb - 1) / wpb, (uint32_t)(ctx->cus * bpc));
+        uint32_t grid = std::min<uint32_t>((waves_wanted + wpb - 1) / wpb, std::max<uint32_t>(1u, (uint32_t)(ctx->cus * bpc) / grid_div));
         grid = std::max(grid, 1u);
         void *kargs[] = {&P};
         HIP_TRY(ctx, hipLaunchKernel(kfn, dim3(grid), dim3(block), kargs, smem, stream));
@@ -1100,6 +1102,8 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
         if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
     }
     if (const char *sp = getenv("RSRT_SMALL_PATHS")) { long long v = atoll(sp); if (v >= 0) ctx->small_paths = (uint64_t)v; } // 0: no pipelining of small jobs (A/B)
+    if (const char *pl = getenv("RSRT_PIPE_LANES")) { int v = atoi(pl); if (v >= 2 && v <= 8) ctx->n_lanes = (uint32_t)v; } // experiment knobs
+    if (const char *pd = getenv("RSRT_PIPE_DIV")) { int v = atoi(pd); if (v >= 1 && v <= 8) ctx->pipe_div = (uint32_t)v; }
     if (const char *ov = getenv("RSRT_OVERLAP")) ctx->overlap = atoi(ov) != 0; // 0: one set of work buffers, every kernel on the caller's stream (A/B)
     if (const char *hy = getenv("RSRT_HYBRID")) ctx->allow_hybrid = atoi(hy) != 0; // 0: mid-size scenes read everything from global memory (A/B)
     if (const char *ty = getenv("RSRT_TRAVERSAL")) ctx->max_traversal = atoi(ty); // cap: 0 generic tree walk, 1 typed leaf loops, 2 + flat small-scene loop, 3 + fixed-order walk (A/B)
@@ -1967,7 +1971,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         P.sample_begin = sample_begin + done;
         P.sample_count = std::min(pass_samples, sample_count - done);
         uint32_t li = 0; // ordinary jobs: lane 0, one after the other (a frame's kernel time is then its own, not its neighbour's too)
-        if (ctx->overlap && pipelined) { li = ctx->next_small_lane; ctx->next_small_lane = (li + 1u) & 3u; }
+        if (ctx->overlap && pipelined) { li = ctx->next_small_lane; ctx->next_small_lane = (li + 1u) % ctx->n_lanes; }
         else ctx->next_small_lane = 1u;
         rsrt_context::Lane &lane = ctx->lanes[li];
         if (need > lane.sample_buf_bytes || need_cold > lane.cold_bytes) { // (grow-only; a reallocation waits for everything in flight)
@@ -1987,7 +1991,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         P.cold_state = lane.cold_state;
         P.work_counter = lane.work_counter;
         rsrt_context::PassEvents pe = {get_event(ctx), get_event(ctx), get_event(ctx)};
-        const rsrt_status pst = enqueue_pass(ctx, P, pe, kfn, block, bpc, smem, per_sample, max_bounces, stream, lane);
+        const rsrt_status pst = enqueue_pass(ctx, P, pe, kfn, block, bpc, smem, per_sample, max_bounces, stream, lane, pipelined ? ctx->pipe_div : 1u);
         if (pst != RSRT_OK) { // nothing of this pass is pending: the three events go back to the pool
             ctx->event_pool.push_back(pe.begin); ctx->event_pool.push_back(pe.traced); ctx->event_pool.push_back(pe.end);
             (void)end_work(ctx, stream); // earlier passes may be in flight

@@ -1606,18 +1606,23 @@ struct WideRay {
     const uint32_t *ref_mem; // the slot's cold column with the record of an earlier call's best hit (read only on an equal t)
     uint32_t win_base, ovf_base, ovf_tri;
     unsigned long long tri_m;
+    // planes and spheres of ONE node (rare inside a mesh's tree, but a ground plane's box is met by most rays): held until the round's
+    // node visits are over and tested then, by all the lanes that hold some, together (RT_WIDE_DEFER_OTHERS)
+    uint32_t oth_base, oth_m, oth_pl;
     RT_DEV void start(V3 o_, V3 d_, V3 inv_, bool anyhit_, const uint32_t *ref_mem_)
     {
         o = o_; d = d_; inv = inv_; anyhit = anyhit_; ref_mem = ref_mem_;
         octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
         win_base = ovf_base = ovf_tri = 0u;
         tri_m = 0ull;
+        oth_base = oth_m = oth_pl = 0u;
     }
     RT_DEV void idle() // a lane without a ray
     {
         w.cur = RT_END; w.grp = 0u;
         win_base = ovf_base = ovf_tri = 0u;
         tri_m = 0ull;
+        oth_base = oth_m = oth_pl = 0u;
         anyhit = false; octant = 0u; ref_mem = nullptr;
         o = d = inv = v3(0.0f, 0.0f, 0.0f);
     }
@@ -1634,6 +1639,17 @@ struct WideRay {
     }                                                                                                               \
     h.t = better ? (t) : h.t;                                                                                       \
     h.ref = better ? (rec) : h.ref;
+
+#ifndef RT_WIDE_DEFER_OTHERS
+#define RT_WIDE_DEFER_OTHERS 0 // 1: the planes / spheres a node visit turns up wait for the end of the round's node visits (0: tested on the spot, lane by lane); measured: 15 k-triangle scene -2 %, suzanne +1 % (profiles/r03_walk_bounds.txt)
+#endif
+// One plane or sphere record of the wide walk (record `rec`; is_plane from the node's type mask)
+#define RT_WIDE_TEST_OTHER(rec, is_plane)                                                                                                             \
+    float4 q[4];                                                                                                                                         \
+    S.template prim_rec<4>((rec), q);                                                                                                                     \
+    const float t = (is_plane) ? plane_t(o, d, v3(q[0].x, q[0].y, q[0].z), v3(q[1].x, q[1].y, q[1].z), v3(q[2].x, q[2].y, q[2].z), v3(q[3].x, q[3].y, q[3].z)) \
+                               : sphere_t(o, d, v3(q[0].x, q[0].y, q[0].z), q[1].y);                                                                    \
+    RT_WIDE_ACCEPT(t, (rec))
 
 // One round's node visits: every lane visits nodes until it holds enough triangles (a shadow ray: any); the wave stops waiting once
 // fewer than `quorum` percent of the `n_started` lanes that hold a ray are still looking.
@@ -1669,18 +1685,15 @@ RT_DEV void wide_nodes(DBG_DECL const View &S, const DevScene &sc, WideRay &r, H
         const uint32_t rec_base = as_u(n[1].w), tri32 = as_u(n[2].w), pl32 = as_u(n[3].w);
         steps += (uint32_t)__popc(lm);
         bool stop = false;
-        // planes and spheres (rare inside a mesh's tree): tested here and now, one at a time
+        // planes and spheres (rare inside a mesh's tree): the first node's that turns some up are held for wide_others; should a second
+        // node bring more while those wait, these are tested here and now, one at a time
         uint32_t oth = lm & ~tri32;
+        if (RT_WIDE_DEFER_OTHERS && oth != 0u && r.oth_m == 0u) { r.oth_base = rec_base; r.oth_m = oth; r.oth_pl = pl32; oth = 0u; }
         while (oth != 0u) {
             DBG_WAVE_TICK(15);
             DBG_ADD(13, 1);
             const uint32_t p = take_lowest(oth);
-            const uint32_t rec = rec_base + p;
-            float4 q[4];
-            S.template prim_rec<4>(rec, q);
-            const float t = ((pl32 >> p) & 1u) ? plane_t(o, d, v3(q[0].x, q[0].y, q[0].z), v3(q[1].x, q[1].y, q[1].z), v3(q[2].x, q[2].y, q[2].z), v3(q[3].x, q[3].y, q[3].z))
-                                               : sphere_t(o, d, v3(q[0].x, q[0].y, q[0].z), q[1].y);
-            RT_WIDE_ACCEPT(t, rec)
+            RT_WIDE_TEST_OTHER(rec_base + p, (pl32 >> p) & 1u)
             if (better & r.anyhit) { stop = true; oth = 0u; }
         }
         // triangles: into the window if they fall inside it, else this node's group is the overflow
@@ -1704,8 +1717,17 @@ RT_DEV void wide_nodes(DBG_DECL const View &S, const DevScene &sc, WideRay &r, H
         } else {
             w.cur = RT_END;
         }
-        if (stop) { w.cur = RT_END; r.tri_m = 0ull; r.ovf_tri = 0u; }
+        if (stop) { w.cur = RT_END; r.tri_m = 0ull; r.ovf_tri = 0u; r.oth_m = 0u; }
         if ((uint32_t)__popcll(__ballot(r.looking())) * 100u < n_started * quorum) break; // wave-uniform
+    }
+    // the planes / spheres held: every lane that holds some tests them now, a record per trip (all of them: nothing of this kind is carried
+    // out of a round)
+    while (r.oth_m != 0u) {
+        DBG_WAVE_TICK(15);
+        DBG_ADD(13, 1);
+        const uint32_t p = take_lowest(r.oth_m);
+        RT_WIDE_TEST_OTHER(r.oth_base + p, (r.oth_pl >> p) & 1u)
+        if (better & r.anyhit) { w.cur = RT_END; r.tri_m = 0ull; r.ovf_tri = 0u; r.oth_m = 0u; }
     }
 }
 
@@ -1747,6 +1769,7 @@ RT_DEV void wide_tris(DBG_DECL const View &S, const DevScene &sc, WideRay &r, Hi
     }
     if (r.ovf_tri != 0u && r.tri_m == 0ull) { r.win_base = r.ovf_base; r.tri_m = r.ovf_tri; r.ovf_tri = 0u; } // the overflow group opens the next window
 }
+#undef RT_WIDE_TEST_OTHER
 #undef RT_WIDE_ACCEPT
 
 // One ray per lane, no refill (GEN's fused first trace, the probe): rounds of node visits and triangle tests until the ray is done, the
