@@ -15,7 +15,7 @@ for label, scene, w, h, spp, mb in [
         ('config 2b: spheres_only.toml 1280x720 64spp', 'spheres_only', 1280, 720, 64, 10),
         ('config 3: cube.toml 1280x720 128spp', 'cube', 1280, 720, 128, 10),
         ('config 3b: suzanne.toml 1280x720 128spp (968 tris, 549 nodes; wide walk, all nodes in LDS)', 'suzanne', 1280, 720, 128, 10),
-        ('config 3c: suzanne grid 4x4 1280x720 32spp (15,488 tris, 8,731 nodes; wide walk, top 352 nodes in LDS)', GRID, 1280, 720, 32, 10),
+        ('config 3c: suzanne grid 4x4 1280x720 32spp (15,488 tris, 8,731 nodes; wide walk, top 192 nodes in LDS)', GRID, 1280, 720, 32, 10),
         ('config 4: house.toml 1920x1080 256spp 8 bounces', 'house', 1920, 1080, 256, 8),
         ('config 4b: house.toml 1920x1080 256spp 10 bounces (the reference constant)', 'house', 1920, 1080, 256, 10),
         ('interactive: house.toml 1920x1080, 1 spp per call (State::render)', 'house', 1920, 1080, 1, 10)]:
