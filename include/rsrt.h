@@ -273,7 +273,7 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n_rays, const float *orig
  * triangles / planes, [4 + k] slot k's records as a mask from there (0: not a leaf); *n_wnodes: capacity in, count out; old_of_new (may be NULL):
  * for every record index the walk uses (whole leaves are reordered so that a wide node's leaf records are contiguous), the
  * index into `primitives` as given.  RSRT_ERR_INVALID_ARGUMENT: the BVH does not qualify (boxes that do not nest, leaves of
- * more than 8 records or that share records, a tree too deep for the walk's register stack) and keeps the fixed-order walk. */
+ * more than 8 records or that share records, a wide tree of more than 25 levels: the walk's eight stack registers + sixteen overflow words) and keeps the fixed-order walk. */
 rsrt_status rsrt_wide_tree_build(const rsrt_primitive_info *primitives, uint32_t n_primitives, const rsrt_bvh_node *bvh_nodes, uint32_t n_bvh_nodes,
                                  float *wnodes_out, uint32_t *n_wnodes, uint32_t *old_of_new);
 

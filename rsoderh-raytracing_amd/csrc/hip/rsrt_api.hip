@@ -373,9 +373,9 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
 #endif
         uint32_t cur = 0, work = 0;
         unsigned long long flat_rem = 0ull;
-        uint32_t wmem[2 + RT_WSTACK]; // (the wide walk parks its stack here between calls, as the pool kernel does in the slot's cold columns)
-        constexpr int T = TRAV == 5 ? 4 : TRAV; // (probe numbering: 4 is the first kernel's stack walk, 5 the wide walk)
-        while (cur != RT_END) trace_dispatch<T>(DBG_ARG S, sc, o, d, prune, false, T == 4 ? 2u : 12u, 50u, cur, h, nullptr, work, flat_rem, wmem, 1u, 60u);
+        uint32_t wmem[RT_WSTATE_WORDS]; // (the wide walk parks its stack here between calls, as the pool kernel does in the slot's cold columns)
+        constexpr int T = TRAV; // (probe numbering: 4 is the first kernel's stack walk, handled above; 5 the wide walk — the form whose stack may overflow, which takes any tree)
+        while (cur != RT_END) trace_dispatch<T>(DBG_ARG S, sc, o, d, prune, false, T >= 4 ? 2u : 12u, 50u, cur, h, nullptr, work, flat_rem, wmem, 1u, 60u);
         // RSRT_PROBE_REPEAT (tools/trace_rate.py): the same query again and again, so that a timing of this kernel is a timing
         // of the traversal and not of staging the scene for 256 rays; the result does not change
         for (uint32_t k = 1; k < repeat; k++) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
             Hit h2;
             h2.t = RT_INFINITY; h2.ref = 0; h2.src = SRC_BVH; h2.u = h2.v = 0.0f;
             cur = 0;
-            while (cur != RT_END) trace_dispatch<T>(DBG_ARG S, sc, o, d, prune, false, T == 4 ? 2u : 12u, 50u, cur, h2, nullptr, work, flat_rem, wmem, 1u, 60u);
+            while (cur != RT_END) trace_dispatch<T>(DBG_ARG S, sc, o, d, prune, false, T >= 4 ? 2u : 12u, 50u, cur, h2, nullptr, work, flat_rem, wmem, 1u, 60u);
             h.t = h2.t; h.ref = h2.ref; h.src = h2.src;
         }
         if (h.did_hit()) hit_barycentrics(S, h, o, d); // as SHADE does: the traversals do not carry u, v
@@ -472,6 +472,7 @@ static const void *pool_function(int trav)
     case 1: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 1>);
     case 3: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 3>);
     case 4: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 4>);
+    case 5: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 5>);
     default: return reinterpret_cast<const void *>(&rt_render_pool_kernel<SV, BLOCK, POOL, 2>);
     }
 }
@@ -585,7 +586,7 @@ struct rsrt_context {
     // scratch for rsrt_resolve_mean_f16 / rsrt_display_srgb8 (grow-only; no per-frame hipMalloc)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
-    int blocks_per_cu[15][RT_N_VARIANTS] = {}; // [scene view * 5 + traversal][kernel variant]
+    int blocks_per_cu[18][RT_N_VARIANTS] = {}; // [scene view * 6 + traversal][kernel variant]
     int kernel_variant = 4; // index into kVariantPool
     int max_traversal = 4; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
     bool allow_flat = true;
@@ -685,7 +686,7 @@ struct WideNode { uint32_t ch[4]; uint32_t n_ch, n_int, first_child; }; // binar
 // the records of a wide node's leaf children are contiguous, and `nodes` with the leaves' first indices pointing there;
 // old_of_new (may be NULL): for every new record index the old one.
 bool build_wide_tree(const rsrt_bvh_node *nodes, uint32_t n_nodes, const rsrt_primitive_info *prims, uint32_t n_prims, std::vector<WideNode> &wide,
-                     std::vector<rsrt_primitive_info> &prims_out, std::vector<rsrt_bvh_node> &nodes_out, std::vector<uint32_t> *old_of_new)
+                     std::vector<rsrt_primitive_info> &prims_out, std::vector<rsrt_bvh_node> &nodes_out, std::vector<uint32_t> *old_of_new, uint32_t *wide_depth = nullptr)
 {
     wide.clear();
     bool ok = n_nodes >= 3 && nodes[0].primitives_len == 0;
@@ -735,7 +736,8 @@ bool build_wide_tree(const rsrt_bvh_node *nodes, uint32_t n_nodes, const rsrt_pr
         for (uint32_t k = 0; k < w.n_int; k++) { queue.push_back(w.ch[k]); level.push_back(level[qi] + 1u); wdepth = std::max(wdepth, level[qi] + 2u); }
         wide.push_back(w);
     }
-    if (wdepth > RT_WSTACK + 1u || wide.size() >= (1u << 27)) { wide.clear(); return false; }
+    if (wdepth > RT_WSTACK + RT_WSPILL + 1u || wide.size() >= (1u << 27)) { wide.clear(); return false; } // (deeper than the walk's stack: registers + overflow columns)
+    if (wide_depth) *wide_depth = wdepth;
     // whole leaves, in the order the wide nodes list them
     prims_out.resize(n_prims);
     nodes_out.assign(nodes, nodes + n_nodes);
@@ -907,7 +909,7 @@ rsrt_status collect_stats(rsrt_context *ctx)
 static bool hybrid_stage(const rsrt_context *ctx, DevScene &sc, int trav, uint32_t room_f4)
 {
     sc.lds_wnodes = sc.lds_prims_f4 = sc.lds_trin_f4 = sc.lds_mats_f4 = 0u;
-    if (trav == 4) {
+    if (trav >= 4) {
         if (ctx->wimg_nodes == 0) return false;
         // (the image was cut for kHybridRoomF4 at upload; a caller with less room — the probe with a deep stack — takes what fits, nodes first)
         sc.lds_wnodes = std::min(ctx->wimg_nodes, room_f4 / 8u);
@@ -946,7 +948,7 @@ int select_traversal(const rsrt_context *ctx, const DevScene &sc, uint32_t max_b
     if (ctx->max_traversal >= 2 && ctx->allow_flat && sc.flat_ok && max_bounces <= RT_FLAT_MAX_BOUNCES) return 2;
     // RSRT_FLAG_PRUNE wants the reference's near-child-first order: a close hit found early is what lets later boxes be
     // skipped (the fixed-order walk prunes 4 % of suzanne's steps, the near-first walk 8 %)
-    if (ctx->max_traversal >= 4 && sc.wide_ok && !(flags & RSRT_FLAG_PRUNE)) return 4;
+    if (ctx->max_traversal >= 4 && sc.wide_ok && !(flags & RSRT_FLAG_PRUNE)) return sc.wide_deep ? 5 : 4; // (5: the same walk with a stack that may overflow into memory)
     if (ctx->max_traversal >= 3 && sc.typed_leaves && !(flags & RSRT_FLAG_PRUNE)) return 3;
     if (ctx->max_traversal >= 1 && sc.typed_leaves) return 1;
     return 0;
@@ -1096,7 +1098,7 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
         return RSRT_ERR_HIP;
     }
     for (int kv = 0; kv < RT_N_VARIANTS; kv++)
-        for (int m = 0; m < 15; m++) (void)hipFuncSetAttribute(variant_function(kv, m / 5, m % 5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int m = 0; m < 18; m++) (void)hipFuncSetAttribute(variant_function(kv, m / 6, m % 6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *kv = getenv("RSRT_KERNEL")) { // see kVariantPool
         int v = atoi(kv);
         if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
@@ -1230,7 +1232,8 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     std::vector<WideNode> wide;
     std::vector<rsrt_primitive_info> prims_perm;
     std::vector<rsrt_bvh_node> nodes_perm;
-    const bool wide_ok = build_wide_tree(nodes, n_nodes, primitives, n_primitives, wide, prims_perm, nodes_perm, nullptr);
+    uint32_t wide_depth = 0;
+    const bool wide_ok = build_wide_tree(nodes, n_nodes, primitives, n_primitives, wide, prims_perm, nodes_perm, nullptr, &wide_depth);
     if (wide_ok) {
         primitives = prims_perm.data();
         nodes = nodes_perm.data();
@@ -1536,6 +1539,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.wnodes = ctx->scene_blob + n_f4 + rank_f4 + pnode_f4 + prank_f4;
     sc.n_wnodes = (uint32_t)wide.size();
     sc.wide_ok = wide_ok ? 1u : 0u;
+    sc.wide_deep = (wide_ok && wide_depth > RT_WSTACK + 1u) ? 1u : 0u;
     sc.lds_wnodes = sc.lds_prims_f4 = sc.lds_trin_f4 = sc.lds_mats_f4 = 0u; // (set per launch, hybrid_stage)
     ctx->wide_image = ctx->scene_blob + n_f4 + rank_f4 + pnode_f4 + prank_f4 + wnode_f4;
     ctx->wimg_nodes = wimg_nodes; ctx->wimg_prims_f4 = wimg_prims_f4; ctx->wimg_trin_f4 = wimg_trin_f4; ctx->wimg_mats_f4 = wimg_mats_f4;
@@ -1936,7 +1940,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     }
     // measured on suzanne and the 15 k-triangle grid (profiles/r02_bvh_knobs.txt): with the quorum vote a round is short, and
     // handing the slot back to the scheduler after about one round beats running several rounds with thinning lanes
-    P.trace_budget = ctx->trace_budget ? ctx->trace_budget : (trav == 4 ? 4u : (trav == 3 ? 6u : 12u)); // (wide walk: rounds, not steps)
+    P.trace_budget = ctx->trace_budget ? ctx->trace_budget : (trav >= 4 ? 4u : (trav == 3 ? 6u : 12u)); // (wide walk: rounds, not steps)
     // a small job behind a kernel that is still running: the 256-thread form, one workgroup per CU, on one of four lanes (see Lane)
     bool pipelined = false;
     if (ctx->overlap && kv == 4 && sv == 1 && (uint64_t)P.n_slots * sample_count <= ctx->small_paths && sample_count <= pass_samples)
@@ -1953,7 +1957,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const void *kfn = variant_function(kv_eff, sv, trav);
     int pipe_blocks = 1; // workgroups per CU of a pipelined small job: four such jobs fill a CU
     if (const char *pb = getenv("RSRT_PIPE_BLOCKS")) { int v = atoi(pb); if (v >= 1 && v <= 4) pipe_blocks = v; } // experiment knob
-    int &bpc = pipelined ? pipe_blocks : ctx->blocks_per_cu[sv * 5 + trav][kv];
+    int &bpc = pipelined ? pipe_blocks : ctx->blocks_per_cu[sv * 6 + trav][kv];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, (int)block, smem);

@@ -84,6 +84,7 @@ struct DevScene {
     // which of the 32 records from there are triangles / planes, [4 + k] slot k's records as a mask from there (0: not a leaf)
     const float4 *wnodes;
     uint32_t n_wnodes, wide_ok;
+    uint32_t wide_deep; // the wide tree has more levels than the walk's register stack holds (RT_WSTACK + 1): TRAV 5
     // the wide walk's LDS image (lds_hybrid == 3; rsrt_api.hip, wide_image): the first lds_wnodes wide nodes, then the first lds_prims_f4 / 4
     // primitive records, then ALL triangle normals and ALL materials if they still fit (0 = none staged); everything else is read from global memory
     uint32_t lds_wnodes, lds_prims_f4, lds_trin_f4, lds_mats_f4;
@@ -1554,41 +1555,68 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
 // (tests/test_box_containment.py); rays with a non-finite 1/d take the fixed-order walk, scenes whose boxes do not nest
 // never get here (rsrt_upload_scene, wide_ok).
 // Order: any (ties go by rank), so depth-first with the pending children of a level as ONE word — first child's node index
-// << 4 | 4-bit mask, a node's interior children being consecutive — and a stack of such words in registers (tree depth <=
-// RT_WSTACK + 1; deeper trees keep the fixed-order walk).  Leaves: the records of a node's leaf children are contiguous
+// << 4 | 4-bit mask, a node's interior children being consecutive — and a stack of such words: the innermost RT_WSTACK in registers, what
+// a deeper tree pushes beyond them in the slot's own columns of the arena (RT_WSPILL more: the bottom of the stack, touched again only when
+// the walk comes back up to the top of the tree; wide depth <= RT_WSTACK + RT_WSPILL + 1, i.e. any scene that fits the device).  Leaves: the records of a node's leaf children are contiguous
 // (the upload permutes whole leaves), so what a lane holds for the primitive loops is one base index + three 32-bit masks.
 // A round = lanes visit nodes until they hold primitives (or a vote ends the wait) -> typed primitive loops.  A ray that is
 // not done when the wave stops (budget, or too few lanes left) parks its stack in the slot's cold columns (`wmem`).
 #define RT_WSTACK 8
+#define RT_WSPILL 16 // stack words beyond the registers, in memory
+// a ray's walk state in memory (`wmem`, words `wstride` apart): [0] next node, [1] pending group, [2 .. 9] the register stack (written when a ray
+// is parked), [10] how many words have overflowed, [11 ..] those words, oldest first (written when they overflow, parked or not)
+#define RT_WSTATE_WORDS (2u + RT_WSTACK + 1u + RT_WSPILL)
 #define RT_WIDE_EMPTY 0xffffffffu
 struct WalkState {
     uint32_t cur;  // node to visit next, RT_END: none
     uint32_t grp;  // pending children of the current level: first child's index << 4 | mask
     uint32_t s0, s1, s2, s3, s4, s5, s6, s7; // pending children of the levels above, s0 the innermost; 0 = none (a shift register: named
                                              // scalars and whole-stack moves, because an indexed array would live in scratch memory)
+    uint32_t spill; // words that have left the registers at the s7 end for memory (> 0 only while all eight registers are in use)
+    RT_DEV void fresh() { cur = 0u; grp = 0u; s0 = s1 = s2 = s3 = s4 = s5 = s6 = s7 = 0u; spill = 0u; }
 };
 static_assert(RT_WSTACK == 8, "WalkState names its eight stack words");
-RT_DEV void wstack_push(WalkState &w, uint32_t v)
+// DEEP: the tree has more wide levels than RT_WSTACK + 1, the stack may overflow (a kernel variant of its own, TRAV 5: the walk of a
+// shallow tree carries neither the test nor the pointer)
+template <bool DEEP>
+RT_DEV void wstack_push(WalkState &w, uint32_t v, uint32_t *m, uint32_t stride)
 {
+    if (DEEP && w.s7 != 0u) { // the registers are full: the oldest word goes to memory (trees deeper than RT_WSTACK + 1 wide levels only)
+        m[(2u + RT_WSTACK + 1u + w.spill) * stride] = w.s7;
+        w.spill++;
+    }
     w.s7 = w.s6; w.s6 = w.s5; w.s5 = w.s4; w.s4 = w.s3; w.s3 = w.s2; w.s2 = w.s1; w.s1 = w.s0; w.s0 = v;
 }
-RT_DEV uint32_t wstack_pop(WalkState &w) // 0 when the stack is empty
+template <bool DEEP>
+RT_DEV uint32_t wstack_pop(WalkState &w, const uint32_t *m, uint32_t stride) // 0 when the stack is empty
 {
     const uint32_t v = w.s0;
     w.s0 = w.s1; w.s1 = w.s2; w.s2 = w.s3; w.s3 = w.s4; w.s4 = w.s5; w.s5 = w.s6; w.s6 = w.s7; w.s7 = 0u;
+    if (DEEP && w.spill != 0u) { // (then the registers were full: the youngest word in memory takes the place that came free)
+        w.spill--;
+#ifdef RT_MUTATE_DROP_SPILL // (mutation check of tests/test_gpu_parity.py::test_wide_walk_stack_overflow_on_a_chain_tree: the overflowed words are lost)
+        w.s7 = 0u;
+#else
+        w.s7 = m[(2u + RT_WSTACK + 1u + w.spill) * stride];
+#endif
+    }
     return v;
 }
+template <bool DEEP>
 RT_DEV void wstate_load(WalkState &w, const uint32_t *m, uint32_t stride)
 {
     w.cur = m[0]; w.grp = m[stride];
     w.s0 = m[2u * stride]; w.s1 = m[3u * stride]; w.s2 = m[4u * stride]; w.s3 = m[5u * stride];
     w.s4 = m[6u * stride]; w.s5 = m[7u * stride]; w.s6 = m[8u * stride]; w.s7 = m[9u * stride];
+    w.spill = DEEP ? m[10u * stride] : 0u;
 }
+template <bool DEEP>
 RT_DEV void wstate_store(const WalkState &w, uint32_t *m, uint32_t stride)
 {
     m[0] = w.cur; m[stride] = w.grp;
     m[2u * stride] = w.s0; m[3u * stride] = w.s1; m[4u * stride] = w.s2; m[5u * stride] = w.s3;
     m[6u * stride] = w.s4; m[7u * stride] = w.s5; m[8u * stride] = w.s6; m[9u * stride] = w.s7;
+    if (DEEP) m[10u * stride] = w.spill;
 }
 
 #ifndef RT_WIDE_HOLD
@@ -1604,14 +1632,16 @@ struct WideRay {
     uint32_t octant;
     WalkState w;
     const uint32_t *ref_mem; // the slot's cold column with the record of an earlier call's best hit (read only on an equal t)
+    uint32_t *wmem;          // the slot's walk state in memory (RT_WSTATE_WORDS words, wstride apart): the stack's overflow, and where a ray is parked
+    uint32_t wstride;
     uint32_t win_base, ovf_base, ovf_tri;
     unsigned long long tri_m;
     // planes and spheres of ONE node (rare inside a mesh's tree, but a ground plane's box is met by most rays): held until the round's
     // node visits are over and tested then, by all the lanes that hold some, together (RT_WIDE_DEFER_OTHERS)
     uint32_t oth_base, oth_m, oth_pl;
-    RT_DEV void start(V3 o_, V3 d_, V3 inv_, bool anyhit_, const uint32_t *ref_mem_)
+    RT_DEV void start(V3 o_, V3 d_, V3 inv_, bool anyhit_, const uint32_t *ref_mem_, uint32_t *wmem_, uint32_t wstride_)
     {
-        o = o_; d = d_; inv = inv_; anyhit = anyhit_; ref_mem = ref_mem_;
+        o = o_; d = d_; inv = inv_; anyhit = anyhit_; ref_mem = ref_mem_; wmem = wmem_; wstride = wstride_;
         octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
         win_base = ovf_base = ovf_tri = 0u;
         tri_m = 0ull;
@@ -1623,7 +1653,7 @@ struct WideRay {
         win_base = ovf_base = ovf_tri = 0u;
         tri_m = 0ull;
         oth_base = oth_m = oth_pl = 0u;
-        anyhit = false; octant = 0u; ref_mem = nullptr;
+        anyhit = false; octant = 0u; ref_mem = nullptr; wmem = nullptr; wstride = 0u;
         o = d = inv = v3(0.0f, 0.0f, 0.0f);
     }
     RT_DEV bool holds() const { return tri_m != 0ull || ovf_tri != 0u; }
@@ -1653,7 +1683,7 @@ struct WideRay {
 
 // One round's node visits: every lane visits nodes until it holds enough triangles (a shadow ray: any); the wave stops waiting once
 // fewer than `quorum` percent of the `n_started` lanes that hold a ray are still looking.
-template <class View>
+template <bool DEEP, class View>
 RT_DEV void wide_nodes(DBG_DECL const View &S, const DevScene &sc, WideRay &r, Hit &h, uint32_t quorum, uint32_t n_started, uint32_t &steps)
 {
     const V3 o = r.o, d = r.d, inv = r.inv;
@@ -1706,10 +1736,10 @@ RT_DEV void wide_nodes(DBG_DECL const View &S, const DevScene &sc, WideRay &r, H
         }
         // where next: the hit interior children become the pending group of a new level (the old one goes on the stack)
         if (im != 0u) {
-            if ((w.grp & 15u) != 0u) wstack_push(w, w.grp);
+            if ((w.grp & 15u) != 0u) wstack_push<DEEP>(w, w.grp, r.wmem, r.wstride);
             w.grp = ((wa & 0x3ffffffu) << 4) | im; // interior children are consecutive: slot k is node (first child) + k
         } else if ((w.grp & 15u) == 0u) {
-            w.grp = wstack_pop(w);
+            w.grp = wstack_pop<DEEP>(w, r.wmem, r.wstride);
         }
         if ((w.grp & 15u) != 0u) {
             w.cur = (w.grp >> 4) + (uint32_t)__builtin_ctz(w.grp);
@@ -1775,19 +1805,19 @@ RT_DEV void wide_tris(DBG_DECL const View &S, const DevScene &sc, WideRay &r, Hi
 // One ray per lane, no refill (GEN's fused first trace, the probe): rounds of node visits and triangle tests until the ray is done, the
 // round budget is spent, or fewer than `stop_quorum` percent of the lanes that came in still hold a ray — then what is held is tested
 // and the lane returns with its stack in `w` (w.cur != RT_END) for the caller to park.
-template <class View>
+template <bool DEEP, class View>
 RT_DEV void trace_wide(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V3 inv, bool anyhit, uint32_t budget, uint32_t quorum, uint32_t stop_quorum,
-                       WalkState &w, Hit &h, const uint32_t *ref_mem, uint32_t &work)
+                       WalkState &w, Hit &h, const uint32_t *ref_mem, uint32_t *wmem, uint32_t wstride, uint32_t &work)
 {
     WideRay r;
-    r.start(o, d, inv, anyhit, ref_mem);
+    r.start(o, d, inv, anyhit, ref_mem, wmem, wstride);
     r.w = w;
     uint32_t steps = 0, rounds = 0;
     const uint32_t started = (uint32_t)__popcll(__ballot(r.w.cur != RT_END));
     bool stopping = false;
     for (;;) {
         DBG_WAVE_TICK(14);
-        if (!stopping) wide_nodes(DBG_ARG S, sc, r, h, quorum, (uint32_t)__popcll(__ballot(true)), steps);
+        if (!stopping) wide_nodes<DEEP>(DBG_ARG S, sc, r, h, quorum, (uint32_t)__popcll(__ballot(true)), steps);
         wide_tris(DBG_ARG S, sc, r, h, quorum, stopping);
         // ---- go on?  A lane leaves when it is done, or when the wave stops and it holds nothing (what it holds is tested first)
         if (stopping) {
@@ -1805,13 +1835,13 @@ RT_DEV void trace_wide(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
 // ------------------------------------------------------------------ which traversal runs
 // TRAV: 0 trace_threaded (any BVH), 1 trace_threaded_typed (no leaf longer than 8 primitives), 2 trace_flat (<= 64
 // records, nested boxes), 3 trace_preorder (no leaf longer than 8 primitives), 4 trace_wide (nested boxes, leaves that
-// share no record, <= 8 primitives a leaf, wide tree no deeper than RT_WSTACK + 1).  One function so that the production
+// share no record, <= 8 primitives a leaf, wide tree no deeper than RT_WSTACK + RT_WSPILL + 1).  One function so that the production
 // kernel's TRACE stage and the ray-query probe (rsrt_cast_rays) run the very same code.  `cur` is the traversal cursor
 // (0 = start at the root, RT_END = done), `h` the best hit so far; the tree walks stop after ~`budget` steps and are
 // resumed by calling again.  `ref_mem`: see trace_preorder.  `work` += box steps + primitive tests of the tree walks
 // (the flat loop, whose work per ray is fixed by the scene, adds nothing).
-// TRAV 4 (trace_wide): `cur` is 0 for a fresh ray, RT_END when done, and otherwise says that the walk's stack waits in `wmem`
-// (this slot's cold columns, `wstride` dwords apart: next node, pending group, RT_WSTACK stack words) — 1.
+// TRAV 4 / 5 (trace_wide; 5 = a tree deeper than the walk's register stack, whose bottom then lives in `wmem`): `cur` is 0 for a fresh ray, RT_END when done, and otherwise says that the walk's stack waits in `wmem`
+// (this slot's cold columns, `wstride` dwords apart: RT_WSTATE_WORDS words, see WalkState) — 1.
 // Rays with a non-finite 1/d take the fixed-order walk, for which `cur` is that walk's cursor; which of the two a ray takes
 // is a function of the ray alone, so a resumed ray reads its `cur` the way it was written.
 template <int TRAV, class View>
@@ -1819,19 +1849,19 @@ RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
                            Hit &h, const uint32_t *ref_mem, uint32_t &work, unsigned long long &flat_rem, uint32_t *wmem = nullptr, uint32_t wstride = 0,
                            uint32_t stop_quorum = 0, bool coherent = false)
 {
-    if (TRAV == 4) {
+    if (TRAV == 4 || TRAV == 5) { // (5: a tree deeper than the register stack)
+        constexpr bool DEEP = TRAV == 5;
         const V3 inv = rt_rcp3(d);
         const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f; // (as for the flat loop below)
         if (finite == 0.0f) {
             WalkState w;
-            w.cur = 0u; w.grp = 0u;
-            w.s0 = w.s1 = w.s2 = w.s3 = w.s4 = w.s5 = w.s6 = w.s7 = 0u;
-            if (cur != 0u) wstate_load(w, wmem, wstride); // parked by an earlier call
-            trace_wide(DBG_ARG S, sc, o, d, inv, anyhit, budget, quorum, stop_quorum, w, h, ref_mem, work);
+            w.fresh();
+            if (cur != 0u) wstate_load<DEEP>(w, wmem, wstride); // parked by an earlier call
+            trace_wide<DEEP>(DBG_ARG S, sc, o, d, inv, anyhit, budget, quorum, stop_quorum, w, h, ref_mem, wmem, wstride, work);
             if (w.cur == RT_END) {
                 cur = RT_END;
             } else {
-                wstate_store(w, wmem, wstride);
+                wstate_store<DEEP>(w, wmem, wstride);
                 cur = 1u;
             }
         } else {

@@ -76,12 +76,14 @@ enum ColdField {
 #define RT_FLAT_BOUNCE_BITS 0xffff00u
 #define RT_FLAT_RESUMED (1u << 24)
 #define RT_FLAT_MAX_BOUNCES 0xffffu // 16 bits of the 25; rsrt_render picks a tree-walk kernel beyond that
-// the wide walk parks an unfinished ray's stack in columns of its own (next node, pending group, RT_WSTACK stack words); only such rays touch them
+// the wide walk parks an unfinished ray's stack in columns of its own, and a deep tree's walk keeps the bottom of its stack there (RT_WSTATE_WORDS
+// columns, rt_device.h WalkState); only such rays touch them
 #define C_WIDE_STATE ((uint32_t)C_COUNT)
-#define C_COUNT_WIDE ((uint32_t)C_COUNT + 2u + RT_WSTACK)
+#define C_COUNT_WIDE ((uint32_t)C_COUNT + 2u + RT_WSTACK)   /* TRAV 4: next node, pending group, the register stack */
+#define C_COUNT_WIDE_DEEP ((uint32_t)C_COUNT + RT_WSTATE_WORDS) /* TRAV 5: + overflow count and overflow words */
 __host__ __device__ constexpr uint32_t pool_cold_columns(int trav)
 {
-    return (RT_COLD_COMPACT && trav == 2) ? (uint32_t)C_COUNT_FLAT : (trav == 4 ? C_COUNT_WIDE : (uint32_t)C_COUNT);
+    return (RT_COLD_COMPACT && trav == 2) ? (uint32_t)C_COUNT_FLAT : (trav == 4 ? C_COUNT_WIDE : (trav == 5 ? C_COUNT_WIDE_DEEP : (uint32_t)C_COUNT));
 }
 enum PoolTag { TAG_FREE = 0, TAG_TRACE = 1, TAG_MISS = 2, TAG_SHADE = 3, TAG_FINISH = 4, TAG_PRIM = 5, TAG_IDLE = 6 };
 // ST_PRIM (flat traversal with RT_FLAT_PRIM_STAGE only): rays whose triangle loop was cut short, scheduled apart from fresh
@@ -109,7 +111,7 @@ enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_FINISH 
 #ifndef RT_REFILL_LIST
 #define RT_REFILL_LIST 128u // entries of the compaction list of the kernels that refill (the others: 64, one per lane)
 #endif
-__host__ __device__ constexpr uint32_t pool_list_dwords(int trav) { return (RT_WIDE_REFILL && trav == 4) ? (uint32_t)RT_REFILL_LIST : 64u; }
+__host__ __device__ constexpr uint32_t pool_list_dwords(int trav) { return (RT_WIDE_REFILL && trav >= 4) ? (uint32_t)RT_REFILL_LIST : 64u; }
 template <uint32_t POOL, int TRAV, bool HOTG>
 struct PoolLayout {
     static constexpr uint32_t kSlotsPerLane = (POOL + 63u) / 64u;
@@ -163,7 +165,8 @@ RT_DEV void store_sample(float *dst, V3 L)
 // TRAV: which traversal TRACE runs — 0 trace_threaded (any BVH), 1 trace_threaded_typed (leaves of <= 8
 // primitives), 2 trace_flat (<= 64 primitive records, nested boxes; rays with a non-finite 1/d fall back to 0),
 // 3 trace_preorder (leaves of <= 8 primitives; fixed order, ties by tabulated visiting rank), 4 trace_wide (4-wide nodes
-// collapsed from the binary tree, a quarter of the dependent fetches; rays with a non-finite 1/d fall back to 3)
+// collapsed from the binary tree, a quarter of the dependent fetches; rays with a non-finite 1/d fall back to 3), 5 trace_wide for a
+// tree deeper than the walk's register stack (the bottom of the stack overflows into the slot's arena columns)
 // SV: where the scene is read from — 0 global memory, 1 the whole image in LDS (256-thread workgroups, several per
 // CU), 2 nodes + escape links in LDS (SceneViewHybrid; BLOCK = 1024: one workgroup per CU shares the copy)
 template <int SV> struct PoolView;
@@ -186,7 +189,8 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     constexpr uint32_t kTCell = kRngHot ? (uint32_t)H_SX : (uint32_t)H_T; // where the extension ray's t waits for SHADE / MISS
     constexpr bool kFlatVote = RT_FLAT_VOTE && kRngHot && kBounceInCt; // a TRACE call may return a flat traversal unfinished
     constexpr bool kPackedMiss = RT_ENV_PACKED != 0 && TRAV == 2; // MISS reads an escaping ray's pmf from the texels' alpha (rt_device.h)
-    constexpr bool kRefill = RT_WIDE_REFILL != 0 && TRAV == 4; // TRACE refills its lanes from a list longer than the wave
+    constexpr bool kRefill = RT_WIDE_REFILL != 0 && TRAV >= 4;
+    constexpr bool kDeep = TRAV == 5; // wide walk of a tree deeper than its register stack // TRACE refills its lanes from a list longer than the wave
     constexpr bool kGenTrace = RT_GEN_TRACE != 0 && TRAV >= 2; // GEN traces the camera ray it has built (the near-first tree walks, kept for RSRT_FLAG_PRUNE, would spill)
     constexpr uint32_t ST_COUNT = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)ST_MAX : (uint32_t)ST_PRIM;
     constexpr uint32_t kTagCut = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)TAG_PRIM : (uint32_t)TAG_TRACE;
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         h.ref = (TRAV >= 3 && !shadow) ? RT_REF_UNKNOWN : ((kFlatVote && cur != 0u) ? ((ct >> CT_SHIFT) & 63u) : 0u);
         const float t_in = h.t;
         trace_dispatch<TRAV>(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, P.trace_budget, TRAV == 2 ? (kFlatVote ? P.flat_quorum : 0u) : P.descend_quorum,
-                             cur, h, &COLD(C_REF, slot), n_work, flat_rem, TRAV == 4 ? &G[C_WIDE_STATE * POOL + slot] : nullptr, POOL, P.stop_quorum, coherent);
+                             cur, h, &COLD(C_REF, slot), n_work, flat_rem, TRAV >= 4 ? &G[C_WIDE_STATE * POOL + slot] : nullptr, POOL, P.stop_quorum, coherent);
         ray_end(slot, ct, h, cur, t_in, flat_rem);
     };
     for (;;) {
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 WideRay r;
                 Hit h;
                 r.idle();
-                r.w.s0 = r.w.s1 = r.w.s2 = r.w.s3 = r.w.s4 = r.w.s5 = r.w.s6 = r.w.s7 = 0u;
+                r.w.fresh(); r.w.cur = RT_END;
                 h.t = RT_INFINITY; h.ref = 0u; h.src = SRC_BVH; h.u = h.v = 0.0f;
                 for (;;) {
                     // free lanes take the next slots of the list
@@ -431,13 +435,9 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                             const V3 inv = rt_rcp3(d);
                             const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f; // (as in trace_dispatch)
                             if (finite == 0.0f) {
-                                r.start(o, d, inv, shadow && anyhit_shadow, &COLD(C_REF, s));
-                                if ((ct >> CT_SHIFT) != 0u) { // parked by an earlier call
-                                    wstate_load(r.w, &G[C_WIDE_STATE * POOL + s], POOL);
-                                } else {
-                                    r.w.cur = 0u; r.w.grp = 0u;
-                                    r.w.s0 = r.w.s1 = r.w.s2 = r.w.s3 = r.w.s4 = r.w.s5 = r.w.s6 = r.w.s7 = 0u;
-                                }
+                                r.start(o, d, inv, shadow && anyhit_shadow, &COLD(C_REF, s), &G[C_WIDE_STATE * POOL + s], POOL);
+                                if ((ct >> CT_SHIFT) != 0u) wstate_load<kDeep>(r.w, r.wmem, POOL); // parked by an earlier call
+                                else r.w.fresh();
                                 have = true;
                             } else { // a non-finite 1/d (axis-parallel rays: next to none): the fixed-order walk, behind the loop; the lane sits out
                                 axial = true;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     const uint32_t n_have = (uint32_t)__popcll(__ballot(have));
                     if (n_have == 0u) { if (next >= n_list) break; continue; }
                     DBG_WAVE_TICK(14);
-                    wide_nodes(DBG_ARG S, sc, r, h, P.descend_quorum, n_have, steps);
+                    wide_nodes<kDeep>(DBG_ARG S, sc, r, h, P.descend_quorum, n_have, steps);
                     wide_tris(DBG_ARG S, sc, r, h, P.descend_quorum, false);
                     if (have && r.done()) { // this ray is through: the lane is free for the next
                         ray_end(my_slot, my_ct, h, RT_END, my_t_in, 0ull);
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                         if (n_act * 100u < n_ref * P.stop_quorum) { // the wave stops here
                             while (__ballot(r.holds()) != 0ull) wide_tris(DBG_ARG S, sc, r, h, P.descend_quorum, true);
                             if (have) {
-                                if (r.w.cur != RT_END) wstate_store(r.w, &G[C_WIDE_STATE * POOL + my_slot], POOL);
+                                if (r.w.cur != RT_END) wstate_store<kDeep>(r.w, &G[C_WIDE_STATE * POOL + my_slot], POOL);
                                 ray_end(my_slot, my_ct, h, r.w.cur == RT_END ? RT_END : 1u, my_t_in, 0ull);
                             }
                             break;

@@ -701,6 +701,71 @@ def test_big_scene_all_global_is_bit_exact(big_env):
     s2.close()
 
 
+@pytest.mark.parametrize("budget,hybrid", [("", "1"), ("1", "1"), ("1", "0")])
+def test_wide_walk_stack_overflow_on_a_chain_tree(budget, hybrid, big_env, monkeypatch):
+    """tests/util.py deck_scene(42): a hand-built chain tree whose wide form has 14 levels, on which a ray along the deck holds up to 13
+    stack words — five more than the walk has registers (test_wide_tree.py shows that on the CPU).  The image, seen along the deck,
+    and a batch of probe rays must be the oracle's bit for bit: with the default budget, and with one round per TRACE call, so that
+    rays are parked and resumed while words sit in the overflow area, nodes staged in LDS or not."""
+    if budget:
+        monkeypatch.setenv("RSRT_TRACE_BUDGET", budget)
+    monkeypatch.setenv("RSRT_HYBRID", hybrid)
+    monkeypatch.setenv("RSRT_FLAT", "0")
+    sc = util.deck_scene(42)
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 96, 64, 0, 4, 10)
+    img, st = gpu_render(sc, big_env, 96, 64, 0, 4, 10)
+    assert np.array_equal(util.bits(img), util.bits(ref))
+    assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+    assert ost["ext_rays"] > 96 * 64 * 4 * 1.2  # (the deck is hit: paths bounce)
+    rng = np.random.default_rng(9)
+    o = (rng.uniform(-0.5, 0.5, (2048, 3)) + [0, 0, 3]).astype(np.float32)
+    d = (rng.normal(size=(2048, 3)) * 0.05 + [0, 0, -1]).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    hits = oracle.cast_rays(util.oracle_scene(sc), o, d, 0, 0)
+    assert hits["did_hit"].sum() > 1024
+    s2 = R.State.new(sc, util.small_env(), 16, 16)
+    for mode in (4 << 1, 5 << 1):
+        got = s2.cast_rays(o, d, mode, 0)
+        assert np.array_equal(np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9), hits.view(np.uint32).reshape(-1, 9)), mode
+    s2.close()
+
+
+@pytest.mark.parametrize("budget", ["", "1"])
+def test_deep_tree_walks_wide_with_its_stack_overflowing_into_memory(budget, big_env, monkeypatch):
+    """suzanne on an 8 x 8 grid (61,952 triangles, binary depth 19): the wide tree has more levels than the walk's eight stack
+    registers, so the bottom of a ray's stack lives in the slot's arena columns (kernel variant TRAV 5).  Bit for bit against the
+    oracle — also with one round per TRACE call (RSRT_TRACE_BUDGET=1: rays are parked and resumed while words sit in the overflow
+    area) — and through the probe, in global memory and with the top of the tree staged in LDS; the wide walk really runs (a third
+    of the fixed-order walk's steps)."""
+    import sys
+    sys.path.insert(0, util.ROOT + "/tools")
+    import make_big_scene
+    if budget:
+        monkeypatch.setenv("RSRT_TRACE_BUDGET", budget)
+    sc = R.Scene.load_toml(make_big_scene.make(8))
+    assert len(sc.triangles) == 61952 and sc.bvh_depth >= 18
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 160, 90, 0, 2, 10, fast=True)
+    img, st = gpu_render(sc, big_env, 160, 90, 0, 2, 10)
+    assert np.array_equal(util.bits(img), util.bits(ref))
+    assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+    wide_steps = st["traversal_steps"] / (st["ext_rays"] + st["shadow_rays"])
+    monkeypatch.setenv("RSRT_TRAVERSAL", "3")
+    img3, st3 = gpu_render(sc, big_env, 160, 90, 0, 2, 10)
+    assert np.array_equal(util.bits(img3), util.bits(ref))
+    assert wide_steps < 0.5 * st3["traversal_steps"] / (st3["ext_rays"] + st3["shadow_rays"]), wide_steps
+    if not budget:
+        rng = np.random.default_rng(6)
+        o = rng.uniform(-12, 12, (4096, 3)).astype(np.float32) + np.float32([0, 2, -8])
+        d = rng.normal(size=(4096, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        hits = oracle.cast_rays(util.oracle_scene(sc), o, d, 0, 0)
+        s2 = R.State.new(sc, util.small_env(), 16, 16)
+        for mode in (4 << 1, 5 << 1, (5 << 1) | 16):
+            got = s2.cast_rays(o, d, mode, 0)
+            assert np.array_equal(np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9), hits.view(np.uint32).reshape(-1, 9)), mode
+        s2.close()
+
+
 @pytest.mark.parametrize("name,w,h,spp,mb", [("house", 128, 72, 6, 8), ("default", 96, 64, 4, 10), ("suzanne", 80, 48, 3, 10)])
 def test_two_pipelines_that_share_only_the_asset_files(name, w, h, spp, mb):
     """Every other image test feeds the oracle the product's OWN preprocessing output (tests/util.py: same BVH, same alias table, same

@@ -80,6 +80,9 @@ def test_wide_tree_structure(name, path):
     assert at == len(sc.primitives) and np.all(seen_nodes == 1)
 
 
+deepest = [0]  # stack words the last walk() held at its deepest
+
+
 def walk(wn, o, d, prim_t):
     """trace_wide for one ray; prim_t(rec) -> hit distance or < 0.  Returns (t, rec) of the closest hit (first of equals by
     record order is NOT modelled: callers compare t)."""
@@ -87,6 +90,7 @@ def walk(wn, o, d, prim_t):
     inv = (np.float32(1.0) / d).astype(np.float32)
     cur, grp, stack, best = 0, 0, [], (np.float32(np.inf), -1)
     visits = 0
+    deepest[0] = 0
     while cur is not None:
         visits += 1
         hm = lm = 0
@@ -113,7 +117,7 @@ def walk(wn, o, d, prim_t):
         if im:
             if grp & 15:
                 stack.append(grp)
-                assert len(stack) <= 8
+                deepest[0] = max(deepest[0], len(stack))  # (beyond eight words the device's stack overflows into memory)
             grp = ((wa & 0x3FFFFFF) << 4) | im
         elif not (grp & 15):
             grp = stack.pop() if stack else 0
@@ -169,3 +173,38 @@ def test_trees_that_do_not_qualify_are_refused():
     bad = R.Scene(sc.materials, sc.spheres, sc.plane_descs, sc.vertices, sc.normals, sc.triangles, sc.camera_desc, planes=sc.planes,
                   primitives=sc.primitives, bvh_nodes=nodes, bvh_depth=sc.bvh_depth)
     assert wide_tree(bad) is None
+
+
+def test_deck_scene_needs_more_stack_than_the_walk_has_registers():
+    """tests/util.py deck_scene: the hand-built chain tree the GPU suite uses for the wide walk's stack overflow
+    (test_gpu_parity.py).  Here, without a GPU: the tree qualifies, the CPU restatement of the walk finds the oracle's hits on it,
+    and a ray along the deck really holds more than eight stack words."""
+    sc = util.deck_scene(42)
+    wn, oon = wide_tree(sc)
+    osc = util.oracle_scene(sc)
+    rng = np.random.default_rng(3)
+    n = 64
+    o = (rng.uniform(-0.5, 0.5, (n, 3)) + [0, 0, 3]).astype(np.float32)
+    d = (rng.normal(size=(n, 3)) * 0.05 + [0, 0, -1]).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ref = oracle.cast_rays(osc, o, d, 1, 0)
+    single = {}
+    for old in range(len(sc.primitives)):
+        nodes1 = np.zeros(1, sc.bvh_nodes.dtype)
+        nodes1["bounds_min"][0, :3] = -1e30
+        nodes1["bounds_max"][0, :3] = 1e30
+        nodes1["primitives_or_second_child_index"], nodes1["primitives_len"] = old, 1
+        one = oracle.Scene(materials=osc.materials, spheres=osc.spheres, planes=osc.planes, vertices=osc.vertices, normals=osc.normals,
+                           triangles=osc.triangles, prims=osc.prims, nodes=nodes1.view(oracle.BVH_NODE))
+        h = oracle.cast_rays(one, o, d, 1, 0)
+        single[old] = np.where(h["did_hit"] != 0, h["distance"], np.float32(-1))
+    most = 0
+    for i in range(n):
+        (t, rec), _ = walk(wn, o[i], d[i], lambda r, i=i: single[int(oon[r])][i])
+        most = max(most, deepest[0])
+        if ref["did_hit"][i]:
+            assert rec >= 0 and t == ref["distance"][i], (i, t, ref["distance"][i])
+        else:
+            assert rec < 0
+    assert ref["did_hit"].sum() > n // 2
+    assert most > 8, most  # the device walk's register stack holds eight

@@ -46,3 +46,65 @@ def small_env(w=64, h=32):
     if (w, h) not in _env_cache:
         _env_cache[(w, h)] = R.Environment.synthetic(w, h)
     return _env_cache[(w, h)]
+
+
+def deck_scene(levels=14):
+    """A hand-built scene whose WIDE tree is deeper than the wide walk's eight stack registers, with few nodes: `levels` pairs of
+    triangles stacked along z (a deck of cards, seen edge-on by the camera), and a binary BVH that is one long chain — node N_k has
+    the small interior node R_k (the two cards of level k) and the chain's next node N_k+1 as children.  Collapsed to four children
+    a node, every third chain node becomes a wide node with FOUR interior children (the chain and three R's); a ray along the deck
+    hits every box, descends the chain first, and leaves three pending siblings behind at every level: its stack grows by a word a
+    level — `levels` // 3 of them.  Boxes nest, leaves hold one record each and share none: the tree qualifies for the wide walk."""
+    from rsoderh_raytracing_amd import types as T
+    base = R.Scene.load_toml(scene_path("default"))
+    verts, tris = [], []
+    for k in range(levels):
+        z = -float(k)
+        s = 1.0 + 0.01 * k  # (slightly different cards: no two records alike)
+        for half in range(2):
+            v0 = len(verts)
+            if half == 0:
+                verts += [(-s, -s, z), (s, -s, z), (s, s, z - 0.25)]
+            else:
+                verts += [(-s, -s, z - 0.5), (s, s, z - 0.5), (-s, s, z - 0.75)]
+            tris.append((v0, v0 + 1, v0 + 2))
+    vertices = np.zeros(len(verts), T.VEC3)
+    vertices["v"] = np.asarray(verts, np.float32)
+    normals = np.zeros(1, T.VEC3)
+    normals["v"][0] = (0.0, 0.0, 1.0)
+    triangles = np.zeros(len(tris), T.TRIANGLE)
+    for i, (a, b, c) in enumerate(tris):
+        triangles[i] = (a, b, c, 0, 0, 0, i % max(1, len(base.materials)))
+    prims = np.zeros(len(tris), T.PRIMITIVE_INFO)
+    prims["primitive_type"], prims["index"] = 2, np.arange(len(tris))
+
+    def tri_box(i):
+        p = vertices["v"][[tris[i][0], tris[i][1], tris[i][2]]]
+        return p.min(axis=0), p.max(axis=0)
+
+    # pre-order with the CHAIN as every node's first child (the wide walk takes a node's children lowest slot first, and only a child
+    # that is entered while siblings still wait pushes a word): N_0 N_1 ... N_(levels-2), R_(levels-1), R_(levels-2) ... R_0
+    n_chain = levels - 1
+    nodes = np.zeros(n_chain + 3 * levels, T.BVH_NODE)
+    r_at = {}
+    at = n_chain
+    for k in range(levels - 1, -1, -1):
+        r_at[k] = at
+        lo0, hi0 = tri_box(2 * k)
+        lo1, hi1 = tri_box(2 * k + 1)
+        nodes[at]["bounds_min"], nodes[at]["bounds_max"] = np.minimum(lo0, lo1), np.maximum(hi0, hi1)
+        nodes[at]["primitives_or_second_child_index"], nodes[at]["primitives_len"], nodes[at]["split_axis"] = at + 2, 0, 2
+        for j, (lo, hi) in enumerate(((lo0, hi0), (lo1, hi1))):
+            nodes[at + 1 + j]["bounds_min"], nodes[at + 1 + j]["bounds_max"] = lo, hi
+            nodes[at + 1 + j]["primitives_or_second_child_index"], nodes[at + 1 + j]["primitives_len"] = 2 * k + j, 1
+        at += 3
+    assert at == len(nodes)
+    for k in range(n_chain - 1, -1, -1):  # N_k: first child = k + 1 (the chain's next node, or R_(levels-1) behind the last), second = R_k
+        a, b = k + 1, r_at[k]
+        nodes[k]["primitives_or_second_child_index"], nodes[k]["primitives_len"], nodes[k]["split_axis"] = b, 0, 2
+        nodes[k]["bounds_min"] = np.minimum(nodes[a]["bounds_min"], nodes[b]["bounds_min"])
+        nodes[k]["bounds_max"] = np.maximum(nodes[a]["bounds_max"], nodes[b]["bounds_max"])
+    cam = np.zeros(1, T.CAMERA_DESC)
+    cam["pos"], cam["yaw"], cam["pitch"], cam["fov_y"] = (0.15, 0.1, 3.0), 0.03, -0.02, 0.9  # (radians) looking down the deck
+    return R.Scene(base.materials, np.zeros(0, T.SPHERE), np.zeros(0, T.PLANE_DESC), vertices, normals, triangles, cam,
+                   planes=np.zeros(0, T.PLANE), primitives=prims, bvh_nodes=nodes, bvh_depth=levels + 1)
