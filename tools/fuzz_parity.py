@@ -1,7 +1,9 @@
 """Differential fuzz: random small scenes (spheres / planes / triangles on a coarse grid, with coincident,
 degenerate and axis-aligned geometry, cameras that look exactly along an axis) rendered by the product and by
 the oracle; every image must match bit for bit and the ray counts must agree.
-python tools/fuzz_parity.py [trials] [first seed]      (run on the GPU box; ~0.4 s per trial)"""
+Every 20th trial is a scene of thousands of small clustered triangles (a tree deeper than the wide walk's register stack), every other 20th a soup of
+large overlapping triangles (long stacks).
+python tools/fuzz_parity.py [trials] [first seed]      (run on the GPU box; ~0.25 s per trial)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -22,6 +24,9 @@ for trial in range(trials):
     nt = int(rng.integers(1, 64 - ns - npl)) if trial % 4 else int(rng.integers(60, 120))  # every 4th: too big for the flat loop
     if trial % 20 == 10:
         nt = int(rng.integers(350, 500))  # image > 24 KB: nodes + escape links in LDS, the rest in global memory
+    deep = trial % 20 in (5, 15)  # trees deeper than the wide walk's register stack (kernel variant TRAV 5; see below)
+    if deep:
+        nt = int(rng.integers(3000, 7000)) if trial % 20 == 5 else int(rng.integers(1200, 2500))
     mats = np.zeros(4, T.MATERIAL)
     mats["color"] = rng.uniform(0.05, 1, (4, 3))
     mats["roughness"] = rng.choice([0.0, 0.05, 0.3, 1.0], 4)
@@ -38,6 +43,13 @@ for trial in range(trials):
     pls["material_id"] = rng.integers(0, 4, npl)
     verts = np.zeros(3 * nt, T.VEC3)
     verts["v"] = np.round(rng.uniform(-3, 3, (3 * nt, 3)) * 2) / 2
+    if deep and trial % 20 == 5:  # thousands of small triangles in a few dense clusters of very different sizes: a deep, lopsided tree
+        centres = rng.uniform(-3, 3, (6, 3))
+        which = rng.choice(6, nt, p=[0.5, 0.25, 0.12, 0.07, 0.04, 0.02])
+        base = centres[which] + rng.normal(size=(nt, 3)) * rng.choice([0.05, 0.3, 1.0], 6)[which][:, None]
+        verts["v"] = (np.repeat(base, 3, axis=0) + rng.uniform(-0.15, 0.15, (3 * nt, 3))).astype(np.float32)
+    elif deep:  # a soup of large triangles: most boxes overlap, a ray meets most of the tree and its stack runs deep
+        verts["v"] = (rng.uniform(-3, 3, (3 * nt, 3)) + np.repeat(rng.uniform(-0.5, 0.5, (nt, 3)), 3, axis=0)).astype(np.float32)
     for k in range(0, nt - 1, 5):  # coincident copies (ties) and zero-area triangles
         verts["v"][3 * k + 3:3 * k + 6] = verts["v"][3 * k:3 * k + 3]
     if nt > 3:
