@@ -714,9 +714,25 @@ bool build_wide_tree(const rsrt_bvh_node *nodes, uint32_t n_nodes, const rsrt_pr
         const double a = dx * dy + dy * dz + dz * dx;
         return a == a ? a : 0.0;
     };
-    std::vector<uint32_t> queue{0u}, level{0u}; // binary roots of the wide nodes, breadth-first
+    // Array order = the order in which nodes are ALLOCATED, and a node's interior children are allocated together, when the node is
+    // expanded (child k = first child + k).  Nodes are expanded largest box first (a ray meets a node about as often as its box is large, and
+    // a child's box lies inside its parent's), so that the array's head — the part the kernel stages in LDS — is the part of the tree the
+    // rays visit most; RSRT_WIDE_ORDER=bfs expands breadth-first instead (the first version; A/B).
+    std::vector<uint32_t> queue{0u}, level{0u}; // binary roots of the wide nodes, in array order
     uint32_t wdepth = 1;
-    for (size_t qi = 0; qi < queue.size(); qi++) {
+    const char *order_env = getenv("RSRT_WIDE_ORDER");
+    const bool by_area = !(order_env && strcmp(order_env, "bfs") == 0);
+    std::vector<std::pair<double, uint32_t>> heap{{area(0), 0u}}; // (box area, array index) of the nodes still to expand
+    size_t bfs_next = 0;
+    while (by_area ? !heap.empty() : bfs_next < queue.size()) {
+        size_t qi;
+        if (by_area) {
+            std::pop_heap(heap.begin(), heap.end(), [](const std::pair<double, uint32_t> &a, const std::pair<double, uint32_t> &b) { return a.first < b.first || (a.first == b.first && a.second > b.second); });
+            qi = heap.back().second;
+            heap.pop_back();
+        } else {
+            qi = bfs_next++;
+        }
         const uint32_t r = queue[qi];
         std::vector<uint32_t> ch{r + 1u, nodes[r].primitives_or_second_child_index};
         while (ch.size() < 4) { // open the interior child with the largest box
@@ -732,10 +748,21 @@ bool build_wide_tree(const rsrt_bvh_node *nodes, uint32_t n_nodes, const rsrt_pr
         for (uint32_t c : ch) if (nodes[c].primitives_len == 0) w.ch[w.n_ch++] = c; // interior children first ...
         w.n_int = w.n_ch;
         for (uint32_t c : ch) if (nodes[c].primitives_len != 0) w.ch[w.n_ch++] = c; // ... then the leaves
-        w.first_child = (uint32_t)queue.size(); // consecutive: breadth-first
-        for (uint32_t k = 0; k < w.n_int; k++) { queue.push_back(w.ch[k]); level.push_back(level[qi] + 1u); wdepth = std::max(wdepth, level[qi] + 2u); }
-        wide.push_back(w);
+        w.first_child = (uint32_t)queue.size(); // consecutive: allocated here and now
+        for (uint32_t k = 0; k < w.n_int; k++) {
+            const uint32_t idx = (uint32_t)queue.size();
+            queue.push_back(w.ch[k]);
+            level.push_back(level[qi] + 1u);
+            wdepth = std::max(wdepth, level[qi] + 2u);
+            if (by_area) {
+                heap.push_back({area(w.ch[k]), idx});
+                std::push_heap(heap.begin(), heap.end(), [](const std::pair<double, uint32_t> &a, const std::pair<double, uint32_t> &b) { return a.first < b.first || (a.first == b.first && a.second > b.second); });
+            }
+        }
+        if (wide.size() < queue.size()) wide.resize(queue.size());
+        wide[qi] = w;
     }
+    wide.resize(queue.size());
     if (wdepth > RT_WSTACK + RT_WSPILL + 1u || wide.size() >= (1u << 27)) { wide.clear(); return false; } // (deeper than the walk's stack: registers + overflow columns)
     if (wide_depth) *wide_depth = wdepth;
     // whole leaves, in the order the wide nodes list them
