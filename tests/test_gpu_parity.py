@@ -701,17 +701,19 @@ def test_big_scene_all_global_is_bit_exact(big_env):
     s2.close()
 
 
-@pytest.mark.parametrize("budget,hybrid", [("", "1"), ("1", "1"), ("1", "0")])
-def test_wide_walk_stack_overflow_on_a_chain_tree(budget, hybrid, big_env, monkeypatch):
-    """tests/util.py deck_scene(42): a hand-built chain tree whose wide form has 14 levels, on which a ray along the deck holds up to 13
-    stack words — five more than the walk has registers (test_wide_tree.py shows that on the CPU).  The image, seen along the deck,
-    and a batch of probe rays must be the oracle's bit for bit: with the default budget, and with one round per TRACE call, so that
-    rays are parked and resumed while words sit in the overflow area, nodes staged in LDS or not."""
+@pytest.mark.parametrize("levels,budget,hybrid,kernel", [(42, "", "1", "4"), (60, "", "1", "4"), (60, "1", "1", "4"), (60, "1", "0", "4"), (60, "1", "0", "1"), (60, "", "0", "3")])
+def test_wide_walk_stack_overflow_on_a_chain_tree(levels, budget, hybrid, kernel, big_env, monkeypatch):
+    """tests/util.py deck_scene: a hand-built chain tree whose wide form has levels / 3 levels, on which a ray along the deck holds up to
+    13 (42 levels) or 19 (60) stack words — more than the walk has registers (test_wide_tree.py shows that on the CPU).  The image, seen
+    along the deck, and a batch of probe rays must be the oracle's bit for bit: with the default budget, and with one round per TRACE
+    call, so that rays are parked and resumed while words sit in the overflow area.  42 levels: the scene's whole image fits LDS (scene
+    view 1); 60: nodes staged in LDS (view 2) or everything in global memory (RSRT_HYBRID=0, view 0) with 160 / 192 / 128-slot pools."""
     if budget:
         monkeypatch.setenv("RSRT_TRACE_BUDGET", budget)
     monkeypatch.setenv("RSRT_HYBRID", hybrid)
+    monkeypatch.setenv("RSRT_KERNEL", kernel)
     monkeypatch.setenv("RSRT_FLAT", "0")
-    sc = util.deck_scene(42)
+    sc = util.deck_scene(levels)
     ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 96, 64, 0, 4, 10)
     img, st = gpu_render(sc, big_env, 96, 64, 0, 4, 10)
     assert np.array_equal(util.bits(img), util.bits(ref))
@@ -731,12 +733,12 @@ def test_wide_walk_stack_overflow_on_a_chain_tree(budget, hybrid, big_env, monke
 
 
 @pytest.mark.parametrize("budget", ["", "1"])
-def test_deep_tree_walks_wide_with_its_stack_overflowing_into_memory(budget, big_env, monkeypatch):
-    """suzanne on an 8 x 8 grid (61,952 triangles, binary depth 19): the wide tree has more levels than the walk's eight stack
-    registers, so the bottom of a ray's stack lives in the slot's arena columns (kernel variant TRAV 5).  Bit for bit against the
-    oracle — also with one round per TRACE call (RSRT_TRACE_BUDGET=1: rays are parked and resumed while words sit in the overflow
-    area) — and through the probe, in global memory and with the top of the tree staged in LDS; the wide walk really runs (a third
-    of the fixed-order walk's steps)."""
+def test_scene_with_a_deep_tree_takes_the_wide_walk(budget, big_env, monkeypatch):
+    """suzanne on an 8 x 8 grid (61,952 triangles, binary depth 19): the wide tree has eleven levels, more than the walk's eight stack
+    registers can always serve, so the scene runs the kernel variant whose stack may overflow into memory (TRAV 5) — on THIS scene no
+    ray ever holds more than eight words (the chain tree above is the test of the overflow itself); what is checked here is that a
+    scene of this size takes the wide walk at all (a third of the fixed-order walk's steps), bit for bit against the oracle, also with
+    one round per TRACE call (RSRT_TRACE_BUDGET=1), and through the probe, in global memory and with the top of the tree staged in LDS."""
     import sys
     sys.path.insert(0, util.ROOT + "/tools")
     import make_big_scene
