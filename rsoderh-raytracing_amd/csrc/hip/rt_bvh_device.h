@@ -14,7 +14,10 @@
 //        LEFT  at b_k     goes to h_k      | RIGHT at p >= L    goes to p - 1, except p == L, which goes to b_m - 1
 //    so one prefix count of the LEFT flags gives every item its place.
 // Shape: level-synchronous.  One workgroup per open node of the level (reductions, buckets, scan, scatter into the other
-// copy of the items); the nodes are numbered breadth-first as they are allocated, and three small passes (subtree sizes
+// copy of the items).  The top of a big tree is ONE workgroup walking a long range, so the passes are written for that case:
+// min / max in registers, combined across a wave by shuffles and across waves by one LDS atomic each (the first version
+// sent every item's twelve keys to the same twelve LDS words: 256 threads taking turns); bucket tables in sixteen private
+// copies; the LEFT-flag prefix from wave ballots, one barrier per 256 items (was a 17-barrier Hillis-Steele scan); the nodes are numbered breadth-first as they are allocated, and three small passes (subtree sizes
 // bottom-up, positions top-down, emit) turn that into the reference's pre-order array (first child = parent + 1,
 // second child's index in the parent, :155-178).  A leaf's primitives are its range of the final item order, so
 // `primitives` is simply the items' (type, index) at the end.
@@ -94,22 +97,42 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void rt_bvh_level_kernel(const BvhTas
     if (blockIdx.x >= n_tasks) return;
     const BvhTask t = tasks[blockIdx.x];
     const uint32_t n = t.end - t.begin, tid = threadIdx.x;
+    constexpr uint32_t kPriv = 16u; // private copies of the bucket tables, by tid >> 4
     __shared__ uint32_t s_box[6], s_cbox[6];             // node box / centroid box as keys
     __shared__ uint32_t s_cnt[RT_BVH_BUCKETS], s_bbox[RT_BVH_BUCKETS][6];
-    __shared__ uint32_t s_scan[RT_BVH_BLOCK];
+    __shared__ uint32_t p_cnt[kPriv][RT_BVH_BUCKETS], p_bbox[kPriv][RT_BVH_BUCKETS][6];
+    __shared__ uint32_t s_wsum[2][RT_BVH_BLOCK / 64];
     __shared__ float pre_mn[RT_BVH_BUCKETS][3], pre_mx[RT_BVH_BUCKETS][3], suf_mn[RT_BVH_BUCKETS][3], suf_mx[RT_BVH_BUCKETS][3]; // (thread 0's sweeps)
     __shared__ uint32_t pre_n[RT_BVH_BUCKETS], suf_n[RT_BVH_BUCKETS];
     __shared__ uint32_t s_misc[8]; // [0] leaf, [1] axis, [2] lo bits, [3] hi bits, [4] best bucket, [5] L, [6] running prefix, [7] pre[L]
     if (tid < 6) { s_box[tid] = tid < 3 ? 0xffffffffu : 0u; s_cbox[tid] = tid < 3 ? 0xffffffffu : 0u; }
-    if (tid < RT_BVH_BUCKETS) { s_cnt[tid] = 0u; for (int k = 0; k < 6; k++) s_bbox[tid][k] = k < 3 ? 0xffffffffu : 0u; }
+    for (uint32_t j = tid; j < kPriv * RT_BVH_BUCKETS; j += RT_BVH_BLOCK) {
+        p_cnt[j / RT_BVH_BUCKETS][j % RT_BVH_BUCKETS] = 0u;
+        for (int k = 0; k < 6; k++) p_bbox[j / RT_BVH_BUCKETS][j % RT_BVH_BUCKETS][k] = k < 3 ? 0xffffffffu : 0u;
+    }
     __syncthreads();
-    // ---- node box, centroid box (:222-234)
-    for (uint32_t i = tid; i < n; i += RT_BVH_BLOCK) {
-        const float4 a = src.bmin[t.begin + i], b = src.bmax[t.begin + i], c = src.cen[t.begin + i];
-        atomicMin(&s_box[0], bvh_key(a.x)); atomicMin(&s_box[1], bvh_key(a.y)); atomicMin(&s_box[2], bvh_key(a.z));
-        atomicMax(&s_box[3], bvh_key(b.x)); atomicMax(&s_box[4], bvh_key(b.y)); atomicMax(&s_box[5], bvh_key(b.z));
-        atomicMin(&s_cbox[0], bvh_key(c.x)); atomicMin(&s_cbox[1], bvh_key(c.y)); atomicMin(&s_cbox[2], bvh_key(c.z));
-        atomicMax(&s_cbox[3], bvh_key(c.x)); atomicMax(&s_cbox[4], bvh_key(c.y)); atomicMax(&s_cbox[5], bvh_key(c.z));
+    // ---- node box, centroid box (:222-234): keys in registers, wave shuffles, one LDS atomic per wave and word
+    {
+        uint32_t lo[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}; // min keys: box min xyz, centroid xyz
+        uint32_t hi[6] = {0u, 0u, 0u, 0u, 0u, 0u};                                                         // max keys: box max xyz, centroid xyz
+        for (uint32_t i = tid; i < n; i += RT_BVH_BLOCK) {
+            const float4 a = src.bmin[t.begin + i], b = src.bmax[t.begin + i], c = src.cen[t.begin + i];
+            const uint32_t ka[3] = {bvh_key(a.x), bvh_key(a.y), bvh_key(a.z)}, kb[3] = {bvh_key(b.x), bvh_key(b.y), bvh_key(b.z)}, kc[3] = {bvh_key(c.x), bvh_key(c.y), bvh_key(c.z)};
+            for (int k = 0; k < 3; k++) {
+                lo[k] = min(lo[k], ka[k]); hi[k] = max(hi[k], kb[k]);
+                lo[3 + k] = min(lo[3 + k], kc[k]); hi[3 + k] = max(hi[3 + k], kc[k]);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1)
+            for (int k = 0; k < 6; k++) {
+                lo[k] = min(lo[k], (uint32_t)__shfl_xor((int)lo[k], off));
+                hi[k] = max(hi[k], (uint32_t)__shfl_xor((int)hi[k], off));
+            }
+        if ((tid & 63u) == 0u)
+            for (int k = 0; k < 3; k++) {
+                atomicMin(&s_box[k], lo[k]); atomicMax(&s_box[3 + k], hi[k]);
+                atomicMin(&s_cbox[k], lo[3 + k]); atomicMax(&s_cbox[3 + k], hi[3 + k]);
+            }
     }
     __syncthreads();
     if (tid == 0) {
@@ -131,13 +154,26 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void rt_bvh_level_kernel(const BvhTas
     if (s_misc[0]) return; // a leaf: its items are final where they are (both copies hold them)
     const uint32_t axis = s_misc[1];
     const float lo = as_f(s_misc[2]), hi = as_f(s_misc[3]);
-    // ---- buckets (:258-276)
-    for (uint32_t i = tid; i < n; i += RT_BVH_BLOCK) {
-        const float4 a = src.bmin[t.begin + i], b = src.bmax[t.begin + i], c = src.cen[t.begin + i];
-        const uint32_t k = bvh_bucket_of(axis == 0 ? c.x : (axis == 1 ? c.y : c.z), lo, hi);
-        atomicAdd(&s_cnt[k], 1u);
-        atomicMin(&s_bbox[k][0], bvh_key(a.x)); atomicMin(&s_bbox[k][1], bvh_key(a.y)); atomicMin(&s_bbox[k][2], bvh_key(a.z));
-        atomicMax(&s_bbox[k][3], bvh_key(b.x)); atomicMax(&s_bbox[k][4], bvh_key(b.y)); atomicMax(&s_bbox[k][5], bvh_key(b.z));
+    // ---- buckets (:258-276): sixteen private tables (neighbouring items tend to share a bucket), folded into one afterwards
+    {
+        const uint32_t pv = tid >> 4;
+        for (uint32_t i = tid; i < n; i += RT_BVH_BLOCK) {
+            const float4 a = src.bmin[t.begin + i], b = src.bmax[t.begin + i], c = src.cen[t.begin + i];
+            const uint32_t k = bvh_bucket_of(axis == 0 ? c.x : (axis == 1 ? c.y : c.z), lo, hi);
+            atomicAdd(&p_cnt[pv][k], 1u);
+            atomicMin(&p_bbox[pv][k][0], bvh_key(a.x)); atomicMin(&p_bbox[pv][k][1], bvh_key(a.y)); atomicMin(&p_bbox[pv][k][2], bvh_key(a.z));
+            atomicMax(&p_bbox[pv][k][3], bvh_key(b.x)); atomicMax(&p_bbox[pv][k][4], bvh_key(b.y)); atomicMax(&p_bbox[pv][k][5], bvh_key(b.z));
+        }
+        __syncthreads();
+        if (tid < RT_BVH_BUCKETS * 7u) { // (bucket, word): count or one of six box keys
+            const uint32_t bk = tid / 7u, wd = tid % 7u;
+            uint32_t acc = wd == 0u ? 0u : (wd <= 3u ? 0xffffffffu : 0u);
+            for (uint32_t q = 0; q < kPriv; q++) {
+                const uint32_t v = wd == 0u ? p_cnt[q][bk] : p_bbox[q][bk][wd - 1u];
+                acc = wd == 0u ? acc + v : (wd <= 3u ? min(acc, v) : max(acc, v));
+            }
+            if (wd == 0u) s_cnt[bk] = acc; else s_bbox[bk][wd - 1u] = acc;
+        }
     }
     __syncthreads();
     if (tid == 0) { // ---- costs (:279-300): prefix / suffix unions, the host's f32 expression, first minimum wins
@@ -169,32 +205,29 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void rt_bvh_level_kernel(const BvhTas
         }
         s_misc[4] = best;
         s_misc[5] = pre_n[best]; // L: the items of buckets <= best
-        s_misc[6] = 0u;
     }
     __syncthreads();
     const uint32_t best = s_misc[4], L = s_misc[5];
-    // ---- the partition (:304-315) as its closed-form permutation.  pre[i] = LEFT items in [0, i)
-    for (uint32_t base = 0; base < n; base += RT_BVH_BLOCK) {
+    // ---- the partition (:304-315) as its closed-form permutation.  pre[i] = LEFT items in [0, i): within a wave from the ballot of the
+    // flags, across waves from the four wave totals (double-buffered: one barrier per 256 items); every thread keeps the running count
+    uint32_t run = 0u;
+    for (uint32_t base = 0, it = 0; base < n; base += RT_BVH_BLOCK, it ^= 1u) {
         const uint32_t i = base + tid;
-        uint32_t flag = 0;
+        bool flag = false;
         if (i < n) {
             const float4 c = src.cen[t.begin + i];
-            flag = bvh_bucket_of(axis == 0 ? c.x : (axis == 1 ? c.y : c.z), lo, hi) <= best ? 1u : 0u;
+            flag = bvh_bucket_of(axis == 0 ? c.x : (axis == 1 ? c.y : c.z), lo, hi) <= best;
         }
-        s_scan[tid] = flag;
+        const unsigned long long m = __ballot(flag);
+        const uint32_t wv = tid >> 6, ln = tid & 63u;
+        if (ln == 0u) s_wsum[it][wv] = (uint32_t)__popcll(m);
         __syncthreads();
-        for (uint32_t off = 1; off < RT_BVH_BLOCK; off <<= 1) { // inclusive scan (Hillis-Steele)
-            const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
-        }
-        const uint32_t run = s_misc[6];
-        if (i < n) scratch_pre[t.begin + i] = (run + s_scan[tid] - flag) | (flag << 31);
-        __syncthreads();
-        if (tid == RT_BVH_BLOCK - 1) s_misc[6] = run + s_scan[tid];
-        __syncthreads();
+        uint32_t before = 0u, total = 0u;
+        for (uint32_t q = 0; q < RT_BVH_BLOCK / 64u; q++) { const uint32_t v = s_wsum[it][q]; before += q < wv ? v : 0u; total += v; }
+        if (i < n) scratch_pre[t.begin + i] = (run + before + (uint32_t)__popcll(m & ((1ull << ln) - 1ull))) | (flag ? 0x80000000u : 0u);
+        run += total;
     }
+    __syncthreads(); // (scratch_pre is read below by other threads than wrote it: the barrier also orders the global stores within the workgroup)
     if (L == 0u || L == n) { // the reference's median fallback (:317-326): unreachable (buckets 0 and 11 are never empty); not built here
         if (tid == 0) atomicExch(&counters[2], 1u);
         return;
