@@ -39,7 +39,7 @@ def test_a_tree_reduction_is_not_the_reference_sum():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,kind", [(8, 4, "sun"), (64, 32, "sun"), (2048, 1024, "sun"), (100, 37, "sun"), (256, 128, "flat"), (300, 200, "noise"), (64, 1, "flat"), (1, 1, "sun"), (128, 64, "wild")])
+@pytest.mark.parametrize("w,h,kind", [(8, 4, "sun"), (64, 32, "sun"), (2048, 1024, "sun"), (100, 37, "sun"), (256, 128, "flat"), (300, 200, "noise"), (64, 1, "flat"), (1, 1, "sun"), (128, 64, "wild"), (96, 48, "zero"), (512, 256, "spike"), (64, 64, "equal")])
 def test_device_alias_table_is_the_host_table_bit_for_bit(w, h, kind):
     """kind: "sun" = the synthetic HDRI (a few hundred very large entries each pair with thousands of small ones: long runs of one
     large), "flat" = every texel within a few per cent of the mean (half the entries are larges that take one small or two and are
@@ -51,6 +51,12 @@ def test_device_alias_table_is_the_host_table_bit_for_bit(w, h, kind):
         v = rng.uniform(0.97, 1.03, (h, w, 3)) if kind == "flat" else 10.0 ** rng.uniform(-2, 2, (h, w, 3))
         if kind == "wild":  # negative texels (weights below zero: 1 - p above 1) among ordinary ones
             v = np.where(rng.uniform(size=(h, w, 1)) < 0.02, -v, v)
+        if kind == "zero":  # a black map: the sum is 0, every p is NaN, nothing is small
+            v = np.zeros((h, w, 3))
+        if kind == "spike":  # one lit texel in a black map: one large takes every small there is
+            v = np.zeros((h, w, 3)); v[h // 3, w // 5] = 7.0
+        if kind == "equal":  # the same colour everywhere (the weights still differ by row)
+            v = np.full((h, w, 3), 0.5)
         rgba = np.ascontiguousarray(np.concatenate([v, np.zeros((h, w, 1))], axis=2).astype(np.float32))
     ref, left_ref = R.AliasTable.build_by_luminance(rgba[:, :, :3])
     oref, oleft = oracle.alias_table(rgba[:, :, :3])
