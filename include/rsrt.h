@@ -21,7 +21,7 @@
  *     sample k of pixel p always uses the reference's RNG seed (pixel_index, k)
  *     (shader.wgsl:1309-1312), so any split over calls / tiles / GPUs gives the same image;
  *   - max_bounces is a run-time argument (the reference's constant is 10, shader.wgsl:232);
- *   - dev_index is fixed at 1 (normal render); the debug views 2/3 are out of scope.
+ *   - dev_index 1 (normal render) is rsrt_render; the developer views 2 / 3 (shader.wgsl:1314-1338) are rsrt_debug_view_f16.
  *
  * Threading: a context is used from one thread at a time, like `State`.  All functions return
  * an rsrt_status (0 = ok) and never throw/abort across the boundary; rsrt_last_error() gives
@@ -228,6 +228,18 @@ rsrt_status rsrt_accumulator_clear(rsrt_context *ctx);
 rsrt_status rsrt_accumulator_download(rsrt_context *ctx, float *host_rgba, size_t n_floats);
 /* out_texture: mean = sum / sample_total rounded to binary16 (shader.wgsl:1369-1372) */
 rsrt_status rsrt_resolve_mean_f16(rsrt_context *ctx, uint32_t sample_total, uint16_t *host_rgba16f, size_t n_halfs);
+
+/* The reference's developer views — what `main` writes to out_texture instead of a render when `dev_index` (bind group 1 binding 3; key
+ * bindings src/camera.rs:283) is 2 or 3, shader.wgsl:1314-1338 — for the bound accumulator's width x height, as RGBA binary16:
+ *   3  the HDRI: texel (x, y) of environment `environment_index`, saturated, alpha 0 (zeros outside the map); the buffer's contents going in
+ *      are ignored;
+ *   2  draws of the alias table: every pixel draws 20 texel indices (seeded by its pixel index and `sample_count`, like a render's pixel) and
+ *      each draw adds 0.1 / 20 to THAT texel's position in out_texture — read, add in f32, store as binary16, alpha 0.  host_rgba16f_inout holds
+ *      out_texture as the previous frame left it and receives the new one.  The shader's invocations race on the texture (which draws survive
+ *      is up to the GPU); this call returns the frame in which every draw lands.
+ * The accumulator is not touched. */
+rsrt_status rsrt_debug_view_f16(rsrt_context *ctx, uint32_t dev_index, uint32_t environment_index, uint32_t sample_count,
+                                uint16_t *host_rgba16f_inout, size_t n_halfs);
 
 /* The display pass (src/shaders/hdr.wgsl `fs_main`, src/hdr.rs:162-200): mean through binary16 ->
  * ACES fit (negatives -> magenta) -> sRGB 8-bit, as the *Srgb surface stores it.  RGBA8, alpha 255.

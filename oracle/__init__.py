@@ -206,3 +206,40 @@ def rng_draws(state, n):
 
 def detmath(fn, a, b=0.0):
     return lib().orc_detmath({"sin": 0, "cos": 1, "atan2": 2, "asin": 3}[fn], a, b)
+
+
+def debug_view(dev_index, env, width, height, sample_count, out_texture=None):
+    """The shader's developer views (shader.wgsl:1314-1338), restated with numpy: what `main` leaves in out_texture ([height, width, 4]
+    float16) when dev_index is 3 (":1333 Display HDRI": the environment's texel under the pixel, saturated, alpha 0; textureLoad outside
+    the map gives zeros) or 2 (":1315 Draw pixels based on distribution": per pixel, seeded as :1309-1312, twenty
+    random_index_in_environment draws (:689-706), each adding vec3(0.1) / f32(20) to that texel's position of out_texture through a
+    binary16 load and store, alpha 0; a store outside the texture is dropped).  The shader's invocations race on the texture; this is
+    the serial execution, pixel after pixel — with equal addends the order does not matter, only that every draw lands."""
+    import numpy as np
+    rgba = np.asarray(env.rgba, np.float32)
+    eh, ew = rgba.shape[:2]
+    out = np.zeros((height, width, 4), np.float16) if out_texture is None else np.array(out_texture, np.float16, copy=True)
+    if dev_index == 3:
+        out[:] = 0
+        h, w = min(eh, height), min(ew, width)
+        out[:h, :w, :3] = np.clip(rgba[:h, :w, :3], 0.0, 1.0).astype(np.float16)
+        return out
+    assert dev_index == 2
+    alias = np.asarray(env.alias).reshape(-1)
+    length = ew * eh
+    step = np.float32(0.1) / np.float32(20)
+    for py in range(height):
+        for px in range(width):
+            draws, _ = rng_draws(rng_seed(py * width + px, sample_count), 40)
+            for k in range(20):
+                u1 = np.float32(lib().orc_u32_to_uniform(C.c_uint32(draws[2 * k])))
+                u2 = np.float32(lib().orc_u32_to_uniform(C.c_uint32(draws[2 * k + 1])))
+                f = np.float32(u1 * np.float32(length))
+                index = min(int(f) if f > 0 else 0, length - 1)
+                entry = alias[index]
+                pick = index if u2 < np.float32(entry["probability"]) else int(entry["alias_index"])
+                x, y = pick % ew, pick // ew
+                if x < width and y < height:
+                    out[y, x, :3] = (out[y, x, :3].astype(np.float32) + step).astype(np.float16)
+                    out[y, x, 3] = 0
+    return out

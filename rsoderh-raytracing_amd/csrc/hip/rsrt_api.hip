@@ -425,6 +425,61 @@ __global__ void rt_mean_f16_kernel(const float4 *accum, size_t n, float inv_is_u
     out[i] = make_ushort4(__half_as_ushort(hx), __half_as_ushort(hy), __half_as_ushort(hz), __half_as_ushort(hw));
 }
 
+// The reference's developer views (shader.wgsl:1314-1338: what `main` writes to out_texture instead of a render when dev_index is 2 or 3).
+// View 3 ("display HDRI", :1333-1338): out[x, y] = saturate(environment texel (x, y)), alpha 0; a pixel outside the map reads zeros.
+__global__ void rt_dev_view_hdri_kernel(const float4 *env_rgba, uint32_t env_w, uint32_t env_h, uint32_t width, uint32_t height, ushort4 *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)width * height) return;
+    const uint32_t x = (uint32_t)(i % width), y = (uint32_t)(i / width);
+    float3 c = make_float3(0.0f, 0.0f, 0.0f);
+    if (x < env_w && y < env_h) { const float4 t = env_rgba[(size_t)y * env_w + x]; c = make_float3(t.x, t.y, t.z); } // (the texel's alpha is the device's own: not looked at)
+    auto sat = [](float v) { return __builtin_fminf(__builtin_fmaxf(v, 0.0f), 1.0f); };
+    out[i] = make_ushort4(__half_as_ushort(__float2half_rn(sat(c.x))), __half_as_ushort(__float2half_rn(sat(c.y))), __half_as_ushort(__float2half_rn(sat(c.z))), __half_as_ushort(__float2half_rn(0.0f)));
+}
+// View 2 ("draw pixels based on distribution", :1314-1332): every pixel draws 20 indices from the environment's alias table, seeded as a
+// render's pixel is (:1309-1312), and adds 0.1 / 20 to THAT texel's position of out_texture.  In the shader the invocations read-modify-write
+// the binary16 texture unordered — which draws survive a frame depends on the GPU's scheduling; this is the frame in which every draw
+// lands: first the draws are counted per texel (integer atomics), then each texel takes its count of `v <- f16(f32(v) + 0.1 / 20)` steps
+// (equal addends: the order of the draws cannot matter), stopping early once a step no longer changes it.
+__global__ void rt_dev_view_count_kernel(const uint4 *alias, uint32_t env_w, uint32_t env_h, uint32_t width, uint32_t height, uint32_t sample_count, uint32_t *counts)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)width * height) return;
+    uint32_t rng = 0;
+    salt_rng(rng, (uint32_t)i);      // pixel_index = y * resolution.x + x
+    salt_rng(rng, sample_count);
+    const uint32_t length = env_w * env_h;
+    for (uint32_t k = 0; k < 20u; k++) { // random_index_in_environment, :689-706
+        const uint32_t index = min(f2u(random_uniform(rng) * (float)length), length - 1u);
+        const uint4 entry = alias[index];
+        const uint32_t pick = random_uniform(rng) < as_f(entry.x) ? index : entry.y;
+        const uint32_t x = pick % env_w, y = pick / env_w;
+        if (x < width && y < height) atomicAdd(&counts[(size_t)y * width + x], 1u); // (a store outside the texture is dropped)
+    }
+}
+__global__ void rt_dev_view_apply_kernel(const uint32_t *counts, size_t n, ushort4 *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = counts[i];
+    if (c == 0u) return;
+    const float step = 0.1f / 20.0f; // vec3(0.1, 0.1, 0.1) / f32(count)
+    ushort4 v = out[i];
+    unsigned short *ch[3] = {&v.x, &v.y, &v.z};
+    for (int k = 0; k < 3; k++) {
+        unsigned short h = *ch[k];
+        for (uint32_t j = 0; j < c; j++) {
+            const unsigned short nx = __half_as_ushort(__float2half_rn(__half2float(__ushort_as_half(h)) + step));
+            if (nx == h) break; // (a fixed point: the remaining steps change nothing)
+            h = nx;
+        }
+        *ch[k] = h;
+    }
+    v.w = __half_as_ushort(__float2half_rn(0.0f)); // textureStore(out_texture, .., vec4(color, 0.))
+    out[i] = v;
+}
+
 // hdr.wgsl fs_main + the *Srgb surface write: mean (through binary16) -> ACES -> sRGB 8-bit
 __global__ void rt_display_kernel(const float4 *accum, size_t n, uint32_t sample_total, uchar4 *out)
 {
@@ -1890,6 +1945,36 @@ rsrt_status rsrt_resolve_mean_f16(rsrt_context *ctx, uint32_t sample_total, uint
     hipLaunchKernelGGL(rt_mean_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->accum, n, 0.0f, sample_total, tmp);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(host, tmp, n * sizeof(ushort4), hipMemcpyDeviceToHost, ctx->stream));
+    if ((st = end_work(ctx, ctx->stream))) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RSRT_OK;
+}
+
+rsrt_status rsrt_debug_view_f16(rsrt_context *ctx, uint32_t dev_index, uint32_t environment_index, uint32_t sample_count, uint16_t *host_inout, size_t n_halfs)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    if (!ctx->accum) return fail(ctx, RSRT_ERR_NOT_READY, "no accumulator");
+    if (dev_index != 2u && dev_index != 3u) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "debug_view: dev_index %u (2: draws of the alias table, 3: the HDRI)", dev_index);
+    if (environment_index >= ctx->envs.size() || !ctx->envs[environment_index].rgba) return fail(ctx, RSRT_ERR_NOT_READY, "debug_view: environment slot %u is empty", environment_index);
+    const Env &e = ctx->envs[environment_index];
+    const size_t n = (size_t)ctx->acc_w * ctx->acc_h;
+    if (!host_inout || n_halfs != n * 4) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "debug_view: expected %zu halfs", n * 4);
+    rsrt_status st = ensure_scratch(ctx, n * sizeof(ushort4) + n * sizeof(uint32_t));
+    if (st || (st = begin_work(ctx, ctx->stream))) return st;
+    ushort4 *tex = static_cast<ushort4 *>(ctx->scratch);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(tex + n);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (dev_index == 3u) {
+        hipLaunchKernelGGL(rt_dev_view_hdri_kernel, dim3(nb), dim3(256), 0, ctx->stream, e.rgba, e.width, e.height, ctx->acc_w, ctx->acc_h, tex);
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(tex, host_inout, n * sizeof(ushort4), hipMemcpyHostToDevice, ctx->stream)); // out_texture as the last frame left it
+        HIP_TRY(ctx, hipMemsetAsync(counts, 0, n * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(rt_dev_view_count_kernel, dim3(nb), dim3(256), 0, ctx->stream, e.alias, e.width, e.height, ctx->acc_w, ctx->acc_h, sample_count, counts);
+        hipLaunchKernelGGL(rt_dev_view_apply_kernel, dim3(nb), dim3(256), 0, ctx->stream, counts, n, tex);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(host_inout, tex, n * sizeof(ushort4), hipMemcpyDeviceToHost, ctx->stream));
     if ((st = end_work(ctx, ctx->stream))) return st;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RSRT_OK;

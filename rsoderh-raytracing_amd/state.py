@@ -21,7 +21,7 @@ FLAG_PRUNE = 2                # opt-in t-pruning; NOT exactly result-preserving 
 
 _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "rsrt_upload_scene",
             "rsrt_upload_environment", "rsrt_set_partition", "rsrt_accumulator_resize", "rsrt_accumulator_bind",
-            "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_render",
+            "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_debug_view_f16", "rsrt_render",
             "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters", "rsrt_display_srgb8",
             "rsrt_selftest_numerics", "rsrt_build_id", "rsrt_wide_tree_build", "rsrt_build_bvh_device",
             "rsrt_partition_owner", "rsrt_partition_mask", "rsrt_partition_tiles", "rsrt_comm_available", "rsrt_comm_unique_id", "rsrt_comm_init", "rsrt_comm_reduce", "rsrt_comm_destroy",
@@ -80,6 +80,7 @@ def lib():
         L.rsrt_accumulator_clear.argtypes = [C.c_void_p]
         L.rsrt_accumulator_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rsrt_resolve_mean_f16.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+        L.rsrt_debug_view_f16.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
         L.rsrt_display_srgb8.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
         L.rsrt_render.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p]
         L.rsrt_synchronize.argtypes = [C.c_void_p]
@@ -278,6 +279,16 @@ class State:
         out = np.empty((self.height, self.width, 4), np.float16)
         n = sample_total if sample_total is not None else self.sample_count
         self._check(self._L.rsrt_resolve_mean_f16(self._ctx, n, _p(out), out.size), "rsrt_resolve_mean_f16")
+        return out
+
+    def debug_view(self, dev_index, out_texture=None, sample_count=None, environment_index=None):
+        """The reference's developer views (shader.wgsl:1314-1338) as out_texture, [H, W, 4] float16: dev_index 3 = the HDRI, 2 = draws
+        of the alias table added onto `out_texture` (the previous frame's; zeros when None).  See rsrt_debug_view_f16."""
+        out = np.zeros((self.height, self.width, 4), np.float16) if out_texture is None else np.ascontiguousarray(out_texture, np.float16).copy()
+        assert out.shape == (self.height, self.width, 4)
+        n = self.sample_count if sample_count is None else sample_count
+        e = self.environment_index if environment_index is None else environment_index
+        self._check(self._L.rsrt_debug_view_f16(self._ctx, dev_index, e, n, _p(out), out.size), "rsrt_debug_view_f16")
         return out
 
     def display_srgb8(self, sample_total=None):

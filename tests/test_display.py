@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 from PIL import Image
 
+import oracle
 import util
 import rsoderh_raytracing_amd as R
 from rsoderh_raytracing_amd import host
@@ -174,3 +175,32 @@ def test_gpu_display_matches_host_and_numpy(tmp_path):
     host.write_png(str(tmp_path / "house.png"), dev)
     assert np.array_equal(np.array(Image.open(tmp_path / "house.png")), dev)
     assert dev[..., :3].std() > 10  # a picture, not a constant
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,ew,eh", [(64, 40, 96, 64), (80, 48, 32, 16)])
+def test_developer_views_match_the_shader_restatement(w, h, ew, eh):
+    """dev_index 2 and 3 (shader.wgsl:1314-1338; rsrt_debug_view_f16) against oracle.debug_view, the numpy restatement of those lines:
+    view 3 shows the environment's texels (zeros outside the map when the frame is larger than it), view 2 adds 0.1 / 20 per draw of the
+    alias table onto the previous out_texture through binary16 — here onto zeros and then onto its own result (a second frame with
+    another sample_count), with the map larger than the frame (draws that fall outside are dropped) and smaller."""
+    sc = R.Scene.load_toml(util.scene_path("default"))
+    env = R.Environment.synthetic(ew, eh)
+    oenv = util.oracle_env(env)
+    st = R.State.new(sc, env, w, h)
+    try:
+        got3 = st.debug_view(3)
+        want3 = oracle.debug_view(3, oenv, w, h, 0)
+        assert np.array_equal(got3.view(np.uint16), want3.view(np.uint16))
+        got2 = st.debug_view(2, sample_count=0)
+        want2 = oracle.debug_view(2, oenv, w, h, 0)
+        assert np.array_equal(got2.view(np.uint16), want2.view(np.uint16))
+        assert want2[..., :3].max() > 0
+        again = st.debug_view(2, out_texture=got2, sample_count=1)  # the next frame brightens what the last one left
+        want_again = oracle.debug_view(2, oenv, w, h, 1, out_texture=want2)
+        assert np.array_equal(again.view(np.uint16), want_again.view(np.uint16))
+        assert float(again[..., :3].astype(np.float32).sum()) > float(got2[..., :3].astype(np.float32).sum())
+        with pytest.raises(R.RsrtError, match="dev_index"):
+            st.debug_view(1)
+    finally:
+        st.close()
