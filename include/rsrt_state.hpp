@@ -153,6 +153,15 @@ public:
         check(rsrt_multi_display_srgb8(m_, sample_count_, out.data(), out.size()));
         return out;
     }
+    // scene.dev_index 2 / 3 (shader.wgsl:1314-1338): out_texture (RGBA binary16) as `main` leaves it for the developer views — 3: the HDRI
+    // under the frame; 2: twenty draws of the alias table per pixel added onto `out_texture` (the previous frame's; zeros when empty)
+    std::vector<uint16_t> debug_view(uint32_t dev_index, std::vector<uint16_t> out_texture = {})
+    {
+        out_texture.resize((size_t)width_ * height_ * 4, 0);
+        const rsrt_status st = rsrt_debug_view_f16(context(0), dev_index, environment_index, sample_count_, out_texture.data(), out_texture.size());
+        if (st != RSRT_OK) throw Error(rsrt_last_error(context(0)));
+        return out_texture;
+    }
     rsrt_stats stats()
     {
         rsrt_stats s;
