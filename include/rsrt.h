@@ -278,8 +278,8 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n_rays, const float *orig
                            uint32_t mode, uint32_t flags, rsrt_hit *out);
 
 /* The wide walk's tree (csrc/hip/rt_device.h, trace_wide) for a BVH, built on the HOST exactly as rsrt_upload_scene builds it
- * for the device (no GPU needed; tests/test_wide_tree.py walks it on the CPU): the binary tree collapsed into 4-wide nodes,
- * breadth-first.  wnodes_out (may be NULL): 32 floats per wide node, 8 x {x, y, z, word} — slot k's exact box is {[2k].xyz,
+ * for the device (no GPU needed; tests/test_wide_tree.py walks it on the CPU): the binary tree collapsed into 4-wide nodes, node 0
+ * the root, a node's interior children consecutive, groups of siblings in the order their parents are expanded (largest box first).  wnodes_out (may be NULL): 32 floats per wide node, 8 x {x, y, z, word} — slot k's exact box is {[2k].xyz,
  * [2k + 1].xyz}; the words are the node's: [0] first interior child's node index (interior children come first and are consecutive)
  * | interior-slot mask << 26, [1] first record of the node's leaf children, [2] / [3] which of the 32 records from there are
  * triangles / planes, [4 + k] slot k's records as a mask from there (0: not a leaf); *n_wnodes: capacity in, count out; old_of_new (may be NULL):

@@ -735,7 +735,7 @@ void make_material_record(const rsrt_material &m, float4 *r)
     r[3] = f4(kd[0], kd[1], kd[2], 1.0f - ps);
 }
 
-// ---- wide walk (rt_device.h, trace_wide): the binary tree collapsed into 4-wide nodes, breadth-first
+// ---- wide walk (rt_device.h, trace_wide): the binary tree collapsed into 4-wide nodes, laid out hottest-first (build_wide_tree)
 struct WideNode { uint32_t ch[4]; uint32_t n_ch, n_int, first_child; }; // binary nodes of the children (interior ones first), index of the first interior child's wide node
 // false: the scene does not qualify (see rsrt_upload_scene).  prims_out / nodes_out: `prims` with whole leaves reordered so that
 // the records of a wide node's leaf children are contiguous, and `nodes` with the leaves' first indices pointing there;
@@ -1305,12 +1305,12 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         for (uint32_t i = 0; i < n_nodes; i++) // (the tables built below are indexed by every node)
             if (!seen[i]) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "bvh node %u is not reachable from the root", i);
     }
-    // ---- wide walk (rt_device.h, trace_wide): the binary tree collapsed into 4-wide nodes, breadth-first.  Needs what makes
+    // ---- wide walk (rt_device.h, trace_wide): the binary tree collapsed into 4-wide nodes, a node's interior children consecutive.  Needs what makes
     // skipping binary nodes exact — every child box inside its parent's — plus leaves of <= 8 records that share none (the
     // records of a wide node's leaf children are made contiguous by moving whole leaves: `primitives` and the leaves' first
     // indices are re-pointed at permuted copies, and everything below is built from those; a record's index is internal to
-    // the device image, ties are decided by the visiting ranks computed from the tree) and a tree shallow enough for the
-    // walk's register stack.
+    // the device image, ties are decided by the visiting ranks computed from the tree) and a wide tree of at most
+    // RT_WSTACK + RT_WSPILL + 1 levels (the walk's stack: eight registers and sixteen overflow words).
     std::vector<WideNode> wide;
     std::vector<rsrt_primitive_info> prims_perm;
     std::vector<rsrt_bvh_node> nodes_perm;
@@ -2221,7 +2221,7 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
     } else {
         sc.lds_float4s = 0;
     }
-    if (trav == 5 && !sc.wide_ok) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: the wide walk needs nested boxes, leaves of at most 8 primitives that share no record, and a shallow enough tree");
+    if (trav == 5 && !sc.wide_ok) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: the wide walk needs nested boxes, leaves of at most 8 primitives that share no record, and a wide tree of at most 25 levels");
     if ((trav == 1 || trav == 3) && !sc.typed_leaves) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: typed leaf loops need leaves of at most 8 primitives");
     if (trav == 2 && (!sc.flat_ok || sv == 2)) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: the flat traversal needs a scene of at most 64 records with nested boxes");
     { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }

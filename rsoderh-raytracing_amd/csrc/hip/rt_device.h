@@ -78,8 +78,8 @@ struct DevScene {
     const float4 *pnodes;
     uint32_t n_pnodes;
     const uint32_t *prim_rank;
-    // wide walk (trace_wide): 4-wide nodes collapsed from the binary tree, breadth-first (a node's interior children are
-    // consecutive), 8 float4 per node: slot k's EXACT box = {[2k].xyz, [2k + 1].xyz}; the .w words are the node's: [0] first
+    // wide walk (trace_wide): 4-wide nodes collapsed from the binary tree, a node's interior children consecutive (groups of
+    // siblings laid out hottest-first: the array's head is what LDS stages), 8 float4 per node: slot k's EXACT box = {[2k].xyz, [2k + 1].xyz}; the .w words are the node's: [0] first
     // interior child's node index | interior-slot mask << 26, [1] first record of the node's leaf children (contiguous), [2] / [3]
     // which of the 32 records from there are triangles / planes, [4 + k] slot k's records as a mask from there (0: not a leaf)
     const float4 *wnodes;
