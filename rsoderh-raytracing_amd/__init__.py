@@ -11,8 +11,11 @@ import os as _os
 
 # pipelined single-sample calls (state.State.render, the reference's interactive mode) want four kernels of a context resident at
 # once, each on a stream of its own; HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and those that share
-# one run one after the other.  Counts only before the process's first HIP call, so it is set as early as this package can.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# one run one after the other.  Counts only before the process's first HIP call, so this HOST-side package asks for 8 as early as
+# it can, unless the variable is already set or RSRT_KEEP_HW_QUEUES=1 says to leave the process environment alone.  (librsrt.so
+# itself never touches the environment: INTEGRATION.md §4.)
+if _os.environ.get("RSRT_KEEP_HW_QUEUES", "0") in ("", "0"):
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import state, types  # noqa: F401,E402
 from .host import AliasTable, Environment, Scene, SceneError, build_bvh, camera_uniform, plane_to_uniform  # noqa: F401

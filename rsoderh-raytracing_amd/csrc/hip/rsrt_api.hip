@@ -54,7 +54,6 @@ struct RenderParams {
     uint32_t chunk_px, n_subtiles; // a chunk covers chunk_px consecutive pixels of a tile (tile_px / n_subtiles)
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
     uint32_t trace_budget, descend_quorum, flat_quorum, stop_quorum;
-    uint32_t refill_min; // wide walk with refill: waiting rays at which TRACE is due (rt_wavepool.h, "2. which stage")
     uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
     float *sample_buf;
     unsigned int *work_counter;
@@ -113,19 +112,16 @@ __device__ __forceinline__ SceneView<false> make_view<false>(const DevScene &sc)
 
 __device__ __forceinline__ SceneViewHybrid make_view_hybrid(const DevScene &sc)
 {
-    const bool wide = sc.lds_hybrid == 3u; // the wide walk's image: wide nodes | primitive records | triangle normals | materials (prefixes, DevScene)
-    const uint32_t o_p = 8u * sc.lds_wnodes, o_t = o_p + sc.lds_prims_f4, o_m = o_t + sc.lds_trin_f4;
+    const bool wide = sc.lds_hybrid == 3u; // the wide walk's image: a prefix of the wide nodes
     return SceneViewHybrid{0u, 2u * sc.n_nodes, sc.prims, sc.tri_normals, sc.materials, sc.fb_spheres, sc.fb_planes, sc.pnodes, sc.lds_float4s, sc.wnodes, sc.lds_hybrid,
-                           wide ? sc.lds_wnodes : 0u, o_p, wide ? sc.lds_prims_f4 : 0u, o_t, wide ? sc.lds_trin_f4 : 0u, o_m, wide ? sc.lds_mats_f4 : 0u};
+                           wide ? sc.lds_wnodes : 0u};
 }
 
 // Copies the scene image into LDS (the arrays are contiguous in one device allocation, in the order
 // make_view<true> assumes).
 __device__ __forceinline__ void stage_scene_lds(const DevScene &sc)
 {
-    // (RT_WNODE_SWIZZLE: the wide walk's nodes are stored swizzled, see SceneViewHybrid::wnode: piece k of node n sits in the node's cell k ^ (n & 7))
-    const uint32_t n_swz = (RT_WNODE_SWIZZLE && sc.lds_hybrid == 3u) ? 8u * sc.lds_wnodes : 0u;
-    for (uint32_t i = threadIdx.x; i < sc.lds_float4s; i += blockDim.x) rt_smem[i < n_swz ? (i ^ ((i >> 3) & 7u)) : i] = sc.lds_src[i];
+    for (uint32_t i = threadIdx.x; i < sc.lds_float4s; i += blockDim.x) rt_smem[i] = sc.lds_src[i];
     __syncthreads();
 }
 
@@ -318,9 +314,8 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
 }
 
 #include "rt_wavepool.h"
-// LDS of the 1024-thread walk kernels (hybrid scene view): sixteen waves' pools — with RT_HOT_GLOBAL only their tag column and compaction list —
-// and beside them the traversal's part of the scene
-static constexpr size_t kHybridPoolBytes = (size_t)(1024 / RT_WAVE) * 4u * ((size_t)(RT_HOT_GLOBAL ? 1u : (uint32_t)H_COUNT) * RT_WALK_POOL + pool_list_dwords(4));
+// LDS of the 1024-thread walk kernels (hybrid scene view): sixteen waves' pools and beside them the traversal's part of the scene
+static constexpr size_t kHybridPoolBytes = (size_t)(1024 / RT_WAVE) * 4u * ((size_t)H_COUNT * RT_WALK_POOL + pool_list_dwords(4));
 static constexpr uint32_t kHybridRoomF4 = (uint32_t)((160 * 1024 - kHybridPoolBytes) / sizeof(float4));
 #include "rt_alias_device.h"
 #include "rt_bvh_device.h"
@@ -497,14 +492,6 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// Pipelined small jobs (rsrt_context::Lane) want four kernels of one context resident at a time, each from a stream of its own; the
-// HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share one run
-// one after the other — measured: 0.85 against 0.63 ms per single-sample call.  Ask for 8, unless the host has said otherwise;
-// this only counts if it happens before the process's first HIP call (INTEGRATION.md says so to hosts that initialise HIP first).
-struct HwQueueHint {
-    HwQueueHint() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-} g_hw_queue_hint;
-
 struct Env {
     float4 *rgba = nullptr;
     uint4 *alias = nullptr;
@@ -571,10 +558,8 @@ struct rsrt_context {
     DevScene scene{};
     bool scene_ready = false;
     uint32_t hybrid_head_f4 = 0, hybrid_pnode_f4 = 0; // mid-size scenes: float4s of nodes + escape links / of the pre-order nodes' top block (0 = none)
-    // ... and the wide walk's LDS image, a copy at the end of scene_blob: the first wimg_nodes wide nodes | the first wimg_prims_f4 / 4 primitive
-    // records | all triangle normals | all materials, as far as kHybridRoomF4 goes in that order (0 nodes = no image)
-    const float4 *wide_image = nullptr;
-    uint32_t wimg_nodes = 0, wimg_prims_f4 = 0, wimg_trin_f4 = 0, wimg_mats_f4 = 0;
+    // ... and the wide walk's LDS image: the first wimg_nodes wide nodes, as many as kHybridRoomF4 holds (0 = no image)
+    uint32_t wimg_nodes = 0;
     // environments
     std::vector<Env> envs;
     // partition
@@ -648,10 +633,20 @@ struct rsrt_context {
     bool allow_hybrid = true;
     uint32_t trace_budget = 0; // traversal steps per TRACE invocation before a ray is re-queued (0: 6 for the fixed-order walk, 12 for the tree walks)
     uint32_t descend_quorum = 30; // fixed-order / wide walk: a descending round ends once fewer than this percentage of its lanes are still descending
-    uint32_t refill_min = 96;  // wide walk with refill: TRACE is due once this many rays wait for it (RSRT_REFILL_MIN)
     uint32_t stop_quorum = 40; // wide walk: a TRACE call ends (the unfinished rays park their stacks) once fewer than this percentage of its lanes are still walking
     uint32_t chunks_per_wave = 32; // work chunks a resident wave should get at least (RSRT_CHUNKS_PER_WAVE): sets samples per chunk, and sub-tiles for small jobs
     uint32_t flat_quorum = 20; // flat traversal: the triangle loop ends once fewer than this percentage of its lanes still hold triangles (0: never)
+    // (every RSRT_* environment knob is read ONCE, in rsrt_context_create)
+    size_t sample_buffer_budget = 16ull << 30; // RSRT_SAMPLE_BUFFER_MB: bytes of sample buffer per pass
+    int pipe_blocks = 1;     // RSRT_PIPE_BLOCKS: workgroups per CU of a pipelined small job (four such jobs fill a CU)
+    int max_blocks_per_cu = 0; // RSRT_BLOCKS_PER_CU: cap on the occupancy the runtime reports (0: none; experiment knob)
+    uint32_t probe_repeat = 1; // RSRT_PROBE_REPEAT: rsrt_cast_rays runs every query this many times (tools/trace_rate.py)
+    // Pipelined small jobs want four kernels of one context resident at a time, each from a stream of its own; the HIP runtime maps a
+    // process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share one run one after the other —
+    // measured: 0.85 against 0.63 ms per single-sample call.  The HOST sets that variable, before its first HIP call; the
+    // library only looks at it, and says so once when it pipelines over fewer queues than it has lanes.
+    int hw_queues = 4;
+    bool hw_queue_warned = false;
     unsigned long long debug_words[32] = {0};
 };
 
@@ -772,11 +767,10 @@ bool build_wide_tree(const rsrt_bvh_node *nodes, uint32_t n_nodes, const rsrt_pr
     // Array order = the order in which nodes are ALLOCATED, and a node's interior children are allocated together, when the node is
     // expanded (child k = first child + k).  Nodes are expanded largest box first (a ray meets a node about as often as its box is large, and
     // a child's box lies inside its parent's), so that the array's head — the part the kernel stages in LDS — is the part of the tree the
-    // rays visit most; RSRT_WIDE_ORDER=bfs expands breadth-first instead (the first version; A/B).
+    // rays visit most.
     std::vector<uint32_t> queue{0u}, level{0u}; // binary roots of the wide nodes, in array order
     uint32_t wdepth = 1;
-    const char *order_env = getenv("RSRT_WIDE_ORDER");
-    const bool by_area = !(order_env && strcmp(order_env, "bfs") == 0);
+    const bool by_area = true; // (breadth-first instead: the first version, 0-1.5 % slower, profiles/r03_walk_bounds.txt)
     std::vector<std::pair<double, uint32_t>> heap{{area(0), 0u}}; // (box area, array index) of the nodes still to expand
     size_t bfs_next = 0;
     while (by_area ? !heap.empty() : bfs_next < queue.size()) {
@@ -990,27 +984,14 @@ rsrt_status collect_stats(rsrt_context *ctx)
 // tree walks their nodes + escape links (all or nothing).  Sets the scene's lds_* fields; false: nothing is staged.
 static bool hybrid_stage(const rsrt_context *ctx, DevScene &sc, int trav, uint32_t room_f4)
 {
-    sc.lds_wnodes = sc.lds_prims_f4 = sc.lds_trin_f4 = sc.lds_mats_f4 = 0u;
+    sc.lds_wnodes = 0u;
     if (trav >= 4) {
-        if (ctx->wimg_nodes == 0) return false;
-        // (the image was cut for kHybridRoomF4 at upload; a caller with less room — the probe with a deep stack — takes what fits, nodes first)
+        // (the image was cut for kHybridRoomF4 at upload; a caller with less room takes what fits)
         sc.lds_wnodes = std::min(ctx->wimg_nodes, room_f4 / 8u);
         if (sc.lds_wnodes == 0) return false;
-        if (sc.lds_wnodes == ctx->wimg_nodes) {
-            room_f4 -= 8u * sc.lds_wnodes;
-            sc.lds_prims_f4 = std::min(ctx->wimg_prims_f4, room_f4 / 4u * 4u);
-            if (sc.lds_prims_f4 == ctx->wimg_prims_f4) {
-                room_f4 -= sc.lds_prims_f4;
-                if (ctx->wimg_trin_f4 <= room_f4) {
-                    sc.lds_trin_f4 = ctx->wimg_trin_f4;
-                    room_f4 -= sc.lds_trin_f4;
-                    if (ctx->wimg_mats_f4 <= room_f4) sc.lds_mats_f4 = ctx->wimg_mats_f4;
-                }
-            }
-        }
-        sc.lds_float4s = 8u * sc.lds_wnodes + sc.lds_prims_f4 + sc.lds_trin_f4 + sc.lds_mats_f4;
+        sc.lds_float4s = 8u * sc.lds_wnodes;
         sc.lds_hybrid = 3u;
-        sc.lds_src = ctx->wide_image;
+        sc.lds_src = sc.wnodes; // a prefix of the array itself
         return true;
     }
     uint32_t head = trav == 3 ? ctx->hybrid_pnode_f4 : ctx->hybrid_head_f4;
@@ -1195,9 +1176,13 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     if (const char *tb = getenv("RSRT_TRACE_BUDGET")) { int v = atoi(tb); if (v > 0) ctx->trace_budget = (uint32_t)v; }
     if (const char *dq = getenv("RSRT_DESCEND_QUORUM")) { int v = atoi(dq); if (v >= 0 && v <= 100) ctx->descend_quorum = (uint32_t)v; }
     if (const char *sq = getenv("RSRT_STOP_QUORUM")) { int v = atoi(sq); if (v >= 0 && v <= 100) ctx->stop_quorum = (uint32_t)v; }
-    if (const char *rm = getenv("RSRT_REFILL_MIN")) { int v = atoi(rm); if (v >= 1 && v <= 4096) ctx->refill_min = (uint32_t)v; }
     if (const char *cw = getenv("RSRT_CHUNKS_PER_WAVE")) { int v = atoi(cw); if (v >= 1 && v <= 4096) ctx->chunks_per_wave = (uint32_t)v; }
     if (const char *fq = getenv("RSRT_FLAT_QUORUM")) { int v = atoi(fq); if (v >= 0 && v <= 100) ctx->flat_quorum = (uint32_t)v; }
+    if (const char *e2 = getenv("RSRT_SAMPLE_BUFFER_MB")) { long v = atol(e2); if (v > 0) ctx->sample_buffer_budget = (size_t)v << 20; }
+    if (const char *pb = getenv("RSRT_PIPE_BLOCKS")) { int v = atoi(pb); if (v >= 1 && v <= 4) ctx->pipe_blocks = v; } // experiment knob
+    if (const char *o = getenv("RSRT_BLOCKS_PER_CU")) { int v = atoi(o); if (v > 0) ctx->max_blocks_per_cu = v; } // experiment knob
+    if (const char *pr = getenv("RSRT_PROBE_REPEAT")) { int v = atoi(pr); if (v > 1 && v <= 4096) ctx->probe_repeat = (uint32_t)v; }
+    if (const char *hq = getenv("GPU_MAX_HW_QUEUES")) { int v = atoi(hq); if (v > 0) ctx->hw_queues = v; }
     for (int m = 0; m < 18; m++) (void)hipFuncSetAttribute(probe_function(m / 6, m % 6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
     snprintf(buf, sizeof buf, "librsrt 0.1; %s (%s); %d CUs", prop.name, prop.gcnArchName, ctx->cus);
@@ -1490,22 +1475,11 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     for (uint32_t e = 0; e < n_pnodes; e++)
         if (plist[e].old != 0xffffffffu) new_id[plist[e].old] = e;
     const size_t pnode_f4 = 2ull * n_pnodes, prank_f4 = (8ull * n_primitives + 3) / 4, wnode_f4 = 8ull * wide.size();
-    // the wide walk's LDS image: what a ray gathers per lane — nodes first, then primitive records, then the shading arrays — as far as the room goes
-    uint32_t wimg_nodes = 0, wimg_prims_f4 = 0, wimg_trin_f4 = 0, wimg_mats_f4 = 0;
-    if (wide_ok) {
-        uint32_t room = kHybridRoomF4;
-        wimg_nodes = std::min<uint32_t>((uint32_t)wide.size(), room / 8u);
-        room -= 8u * wimg_nodes;
-        if (!RT_HOT_GLOBAL) room = 0u; // (the hybrid view reads nothing but nodes from LDS then)
-        wimg_prims_f4 = 4u * std::min<uint32_t>(n_primitives, room / 4u);
-        room -= wimg_prims_f4;
-        if (wimg_prims_f4 == 4u * n_primitives && 3ull * n_triangles <= room) { wimg_trin_f4 = 3u * n_triangles; room -= wimg_trin_f4; }
-        if (wimg_prims_f4 == 4u * n_primitives && 4ull * n_materials <= room) { wimg_mats_f4 = 4u * n_materials; room -= wimg_mats_f4; }
-    }
-    const size_t wimg_f4 = 8ull * wimg_nodes + wimg_prims_f4 + wimg_trin_f4 + wimg_mats_f4;
+    // the wide walk's LDS image: the head of the wide-node array (hottest first), as far as the room beside the pools goes
+    const uint32_t wimg_nodes = wide_ok ? std::min<uint32_t>((uint32_t)wide.size(), kHybridRoomF4 / 8u) : 0u;
     // ---- build the device image: nodes | prims | escape links | tri normals | materials | fb spheres | fb planes
     const size_t n_f4 = 2ull * n_nodes + 4ull * n_primitives + 3ull * n_triangles + 4ull * n_materials + 4ull * n_spheres + 4ull * n_planes + esc_f4 + flat_f4;
-    std::vector<float4> img(n_f4 + rank_f4 + pnode_f4 + prank_f4 + wnode_f4 + wimg_f4); // what follows the LDS image: flat ranks | pre-order nodes | record ranks | wide nodes | the wide walk's LDS image
+    std::vector<float4> img(n_f4 + rank_f4 + pnode_f4 + prank_f4 + wnode_f4); // what follows the LDS image: flat ranks | pre-order nodes | record ranks | wide nodes
     float4 *p = img.data();
     float4 *p_nodes = p;
     bool typed_leaves = true;
@@ -1589,16 +1563,6 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     }
     if (n_primitives) memcpy(p_pnodes + pnode_f4, prim_rank.data(), prim_rank.size() * sizeof(uint32_t));
     fill_wide_nodes(wide, nodes, primitives, p_pnodes + pnode_f4 + prank_f4);
-    { // the wide walk's LDS image: copies of the arrays' heads, in the order SceneViewHybrid expects
-        float4 *q = p_pnodes + pnode_f4 + prank_f4 + wnode_f4;
-        if (wimg_nodes) memcpy(q, p_pnodes + pnode_f4 + prank_f4, 8ull * wimg_nodes * sizeof(float4));
-        q += 8ull * wimg_nodes;
-        if (wimg_prims_f4) memcpy(q, p_prims, (size_t)wimg_prims_f4 * sizeof(float4));
-        q += wimg_prims_f4;
-        if (wimg_trin_f4) memcpy(q, p_trin, (size_t)wimg_trin_f4 * sizeof(float4));
-        q += wimg_trin_f4;
-        if (wimg_mats_f4) memcpy(q, p_mats, (size_t)wimg_mats_f4 * sizeof(float4));
-    }
 
     { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     if (ctx->scene_blob) { (void)hipFree(ctx->scene_blob); ctx->scene_blob = nullptr; }
@@ -1622,17 +1586,16 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.n_wnodes = (uint32_t)wide.size();
     sc.wide_ok = wide_ok ? 1u : 0u;
     sc.wide_deep = (wide_ok && wide_depth > RT_WSTACK + 1u) ? 1u : 0u;
-    sc.lds_wnodes = sc.lds_prims_f4 = sc.lds_trin_f4 = sc.lds_mats_f4 = 0u; // (set per launch, hybrid_stage)
-    ctx->wide_image = ctx->scene_blob + n_f4 + rank_f4 + pnode_f4 + prank_f4 + wnode_f4;
-    ctx->wimg_nodes = wimg_nodes; ctx->wimg_prims_f4 = wimg_prims_f4; ctx->wimg_trin_f4 = wimg_trin_f4; ctx->wimg_mats_f4 = wimg_mats_f4;
+    sc.lds_wnodes = 0u; // (set per launch, hybrid_stage)
+    ctx->wimg_nodes = wimg_nodes;
     sc.flat_ok = flat_ok ? 1u : 0u;
     sc.n_cull = 0; sc.cull_always = 0xffffffffu;
     if (flat_ok) { // the interior nodes two levels below the root and the leaves under each (rt_device.h, RT_FLAT_CULL)
         std::vector<uint32_t> leaf_index(n_nodes, 0u);
         for (size_t k = 0; k < leaf_nodes.size(); k++) leaf_index[leaf_nodes[k]] = (uint32_t)k;
         std::vector<std::pair<uint32_t, uint32_t>> st{{0u, 0u}}; // node, depth
-        uint32_t always = 0u, cull_depth = 2u;
-        if (const char *cd = getenv("RSRT_CULL_DEPTH")) { int v = atoi(cd); if (v >= 1 && v <= 3) cull_depth = (uint32_t)v; } // experiment knob (2 measured best)
+        uint32_t always = 0u;
+        const uint32_t cull_depth = 2u; // (1 / 2 / 3 below the root measured alike, profiles/r03_fusion_ab.txt)
         while (!st.empty()) {
             auto [i, d] = st.back();
             st.pop_back();
@@ -2032,13 +1995,11 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.descend_quorum = ctx->descend_quorum;
     P.flat_quorum = ctx->flat_quorum;
     P.stop_quorum = ctx->stop_quorum;
-    P.refill_min = ctx->refill_min;
     P.stats = ctx->dev_stats;
     if (P.n_slots == 0) return RSRT_OK;
 
     // sample buffer: [samples of this pass][slot][3]; passes bound its size
-    size_t budget = 16ull << 30;
-    if (const char *e = getenv("RSRT_SAMPLE_BUFFER_MB")) { long v = atol(e); if (v > 0) budget = (size_t)v << 20; }
+    const size_t budget = ctx->sample_buffer_budget;
     const size_t per_sample = (size_t)P.n_slots * 3 * sizeof(float);
     uint32_t pass_samples = (uint32_t)std::max<size_t>(1, std::min<size_t>(sample_count, budget / per_sample));
     pass_samples = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(pass_samples, 0xffffffffull / P.n_slots)); // slot ids are 32-bit
@@ -2062,23 +2023,26 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const uint32_t pool = sv == 2 ? RT_WALK_POOL : ((kv_eff == 4 && !big) ? 160u : kVariantPool[kv_eff]);
     const uint32_t block = (sv == 2 || big) ? 1024u : (uint32_t)RT_BLOCK;
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
-    const bool hot_global = RT_HOT_GLOBAL && sv == 2; // the walk kernels keep only the tag column of the hot path state in LDS (rt_wavepool.h)
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
-                                : scene_bytes + (size_t)(block / RT_WAVE) * 4u * ((size_t)(hot_global ? 1u : (uint32_t)H_COUNT) * pool + pool_list_dwords(trav));
+                                : scene_bytes + (size_t)(block / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + pool_list_dwords(trav));
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
     const void *kfn = variant_function(kv_eff, sv, trav);
-    int pipe_blocks = 1; // workgroups per CU of a pipelined small job: four such jobs fill a CU
-    if (const char *pb = getenv("RSRT_PIPE_BLOCKS")) { int v = atoi(pb); if (v >= 1 && v <= 4) pipe_blocks = v; } // experiment knob
+    int pipe_blocks = ctx->pipe_blocks; // workgroups per CU of a pipelined small job: four such jobs fill a CU
+    if (pipelined && !ctx->hw_queue_warned && ctx->hw_queues < (int)ctx->n_lanes + 1) { // (the lanes' streams and the caller's)
+        ctx->hw_queue_warned = true;
+        fprintf(stderr, "librsrt: pipelining single-sample calls over %u streams on %d hardware queues: set GPU_MAX_HW_QUEUES=8 before the first HIP call (INTEGRATION.md)\n",
+                ctx->n_lanes, ctx->hw_queues);
+    }
     int &bpc = pipelined ? pipe_blocks : ctx->blocks_per_cu[sv * 6 + trav][kv];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, (int)block, smem);
         if (e != hipSuccess || nb <= 0) nb = 1;
         bpc = std::min(nb, 8);
-        if (const char *o = getenv("RSRT_BLOCKS_PER_CU")) { int v = atoi(o); if (v > 0) bpc = std::min(bpc, v); } // experiment knob
+        if (ctx->max_blocks_per_cu > 0) bpc = std::min(bpc, ctx->max_blocks_per_cu);
     }
 
-    const size_t need_cold = kv != 0 ? (size_t)ctx->cus * bpc * (block / RT_WAVE) * (pool_cold_columns(trav) + (hot_global ? (uint32_t)H_CT : 0u)) * pool * sizeof(uint32_t) : 0; // cold path-state arena: one block of columns per wave that can be resident
+    const size_t need_cold = kv != 0 ? (size_t)ctx->cus * bpc * (block / RT_WAVE) * pool_cold_columns(trav) * pool * sizeof(uint32_t) : 0; // cold path-state arena: one block of columns per wave that can be resident
     // the context's buffers are shared by every call: order this stream after whatever ran last (another stream's
     // render, rsrt_accumulator_clear on the context's own stream, ...) — with lanes, enqueue_pass orders each resolve itself
     if (!ctx->overlap && (st = begin_work(ctx, stream))) return st;
@@ -2091,7 +2055,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         else ctx->next_small_lane = 1u;
         rsrt_context::Lane &lane = ctx->lanes[li];
         if (need > lane.sample_buf_bytes || need_cold > lane.cold_bytes) { // (grow-only; a reallocation waits for everything in flight)
-            if ((st = sync_all(ctx))) { (void)end_work(ctx, stream); return st; }
+            if ((st = sync_all(ctx))) { if (!ctx->overlap) (void)end_work(ctx, stream); return st; }
             if (need > lane.sample_buf_bytes) {
                 if (lane.sample_buf) { (void)hipFree(lane.sample_buf); lane.sample_buf = nullptr; lane.sample_buf_bytes = 0; }
                 HIP_TRY(ctx, hipMalloc(&lane.sample_buf, need));
@@ -2110,7 +2074,9 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         const rsrt_status pst = enqueue_pass(ctx, P, pe, kfn, block, bpc, smem, per_sample, max_bounces, stream, lane, pipelined ? ctx->pipe_div : 1u);
         if (pst != RSRT_OK) { // nothing of this pass is pending: the three events go back to the pool
             ctx->event_pool.push_back(pe.begin); ctx->event_pool.push_back(pe.traced); ctx->event_pool.push_back(pe.end);
-            (void)end_work(ctx, stream); // earlier passes may be in flight
+            // earlier passes may be in flight.  With lanes the chain's end stays where the last successful pass recorded it (its lane's
+            // resolve): recording it on the caller's stream here would drop the dependency on those resolves
+            if (!ctx->overlap) (void)end_work(ctx, stream);
             return pst;
         }
         ctx->pending_events.push_back(pe);
@@ -2235,8 +2201,7 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
     if (e == hipSuccess) {
         const size_t smem = (size_t)sc.lds_float4s * sizeof(float4) + (trav == 4 ? (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t) : 0u); // (only the stack walk has a stack)
         if (smem > 160 * 1024) { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: needs %zu bytes of LDS", smem); }
-        uint32_t repeat = 1;
-        if (const char *pr = getenv("RSRT_PROBE_REPEAT")) { int v = atoi(pr); if (v > 1 && v <= 4096) repeat = (uint32_t)v; }
+        uint32_t repeat = ctx->probe_repeat;
         void *kargs[] = {&sc, &n, &d_o, &d_d, &mode, &flags, &repeat, &d_h};
         e = hipLaunchKernel(probe_function(sv, trav), dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), kargs, smem, ctx->stream);
     }

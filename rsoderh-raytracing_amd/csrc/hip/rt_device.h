@@ -68,7 +68,7 @@ struct DevScene {
     uint32_t flat_ok, n_leaves;
     uint32_t tri_mask_lo, tri_mask_hi, plane_mask_lo, plane_mask_hi; // which records are triangles / planes
     const uint32_t *flat_rank; // [8 octants][16]: byte p = position of record p in that octant's depth-first visiting order
-    // two-level cull of the flat loop for COHERENT batches (GEN's fused trace; RT_FLAT_CULL): the interior nodes two levels below the
+    // two-level cull of the flat loop for COHERENT batches (GEN's fused trace): the interior nodes two levels below the
     // root, each with the leaves under it as a mask; leaves above that level are always tested
     float cull_min[8][3], cull_max[8][3];
     uint32_t cull_mask[8], cull_always, n_cull;
@@ -85,9 +85,8 @@ struct DevScene {
     const float4 *wnodes;
     uint32_t n_wnodes, wide_ok;
     uint32_t wide_deep; // the wide tree has more levels than the walk's register stack holds (RT_WSTACK + 1): TRAV 5
-    // the wide walk's LDS image (lds_hybrid == 3; rsrt_api.hip, wide_image): the first lds_wnodes wide nodes, then the first lds_prims_f4 / 4
-    // primitive records, then ALL triangle normals and ALL materials if they still fit (0 = none staged); everything else is read from global memory
-    uint32_t lds_wnodes, lds_prims_f4, lds_trin_f4, lds_mats_f4;
+    // the wide walk's LDS image (lds_hybrid == 3): the first lds_wnodes wide nodes; everything else is read from global memory
+    uint32_t lds_wnodes;
     const float4 *lds_src; // what stage_scene_lds copies (lds_float4s float4s): the image, nodes | escape links, or the pre-order nodes
 };
 
@@ -106,14 +105,6 @@ template <bool LDS>
 struct SceneView;
 
 extern __shared__ float4 rt_smem[];
-// RT_HOT_GLOBAL (rt_wavepool.h): the walk kernels keep only the tag column of the hot path state in LDS and stage nodes, primitive records, normals
-// and materials there instead.  Measured (profiles/r03_hot_global.txt): not faster — 0: the hybrid view stages wide nodes only, the rest is global
-#ifndef RT_HOT_GLOBAL
-#define RT_HOT_GLOBAL 0
-#endif
-#ifndef RT_WNODE_SWIZZLE
-#define RT_WNODE_SWIZZLE 0 // the wide walk's LDS nodes: piece k of node n in cell k ^ (n & 7) (bank conflicts, SceneViewHybrid::wnode; measured, not faster)
-#endif
 
 template <>
 struct SceneView<true> {
@@ -174,8 +165,9 @@ struct SceneView<false> {
     RT_DEV uint32_t esc(uint32_t i) const { return reinterpret_cast<const uint32_t *>(escape)[i]; }
 };
 
-// Mid-size scenes (suzanne: 97 KB of traversal data): what every box step touches — nodes and escape links —
-// in LDS, shared by ONE 1024-thread workgroup per CU; primitive records and the shading arrays in global memory.
+// Mid-size and big scenes: the head of the chosen traversal's node array in LDS, shared by ONE 1024-thread workgroup per CU
+// (DevScene::lds_hybrid says which: 1 nodes | escape links of the tree walks, 2 the top block of the fixed-order walk's elements, 3 the
+// first n_w wide nodes); primitive records and the shading arrays are read from global memory.
 struct SceneViewHybrid {
     uint32_t o_nodes, o_esc;
     const float4 *prims, *tri_normals, *materials, *fb_spheres, *fb_planes;
@@ -183,80 +175,35 @@ struct SceneViewHybrid {
     uint32_t lds_f4;
     const float4 *wnodes;
     uint32_t head; // what the staged head holds (DevScene::lds_hybrid): the accessors of the other traversals read global memory
-    // head == 3, the wide walk's image: [wide nodes][primitive records][triangle normals][materials], each a PREFIX of its array (0: none)
-    uint32_t n_w, o_p, n_p_f4, o_t, n_t_f4, o_m, n_m_f4;
+    uint32_t n_w;  // head == 3: wide nodes staged (a prefix of the array)
     // One array element: from LDS when it lies in the staged prefix, else from global memory.  Written as an unconditional ds_read (of
     // element 0 for the lanes that are past the prefix) plus a global load under a branch: a select between the two POINTERS makes the
     // compiler emit flat loads, which take the texture path even for LDS and are waited for one by one (measured on the fixed-order
     // walk: 12 % slower than three plain loads per step).
-#define RT_LDS_OR_GLOBAL(in_lds, lds_index, global_expr)          \
-    float4 r = rt_smem[(in_lds) ? (lds_index) : 0u];               \
-    if (!(in_lds)) r = (global_expr);                              \
-    return r;
-    // Wide node i: in LDS a node's eight 16-byte pieces may be stored XOR-swizzled by the node's index (RT_WNODE_SWIZZLE): every lane reads
-    // piece k of ITS node at the same time, and with plain 128-byte nodes those reads fall on two of the sixteen 16-byte cells of the
-    // 256-byte bank row (tools/gather_rate.hip); measured on the round-3 kernel, where LDS was idle: 1-2 % SLOWER (the address arithmetic).
     RT_DEV void wnode(uint32_t i, float4 (&n)[8]) const
     {
         const bool in_lds = i < n_w;
         const uint32_t k0 = in_lds ? 8u * i : 0u;
-        const uint32_t sw = RT_WNODE_SWIZZLE ? (in_lds ? (i & 7u) : 0u) : 0u;
 #pragma unroll
-        for (int k = 0; k < 8; k++) n[k] = rt_smem[k0 + ((uint32_t)k ^ sw)];
+        for (int k = 0; k < 8; k++) n[k] = rt_smem[k0 + (uint32_t)k];
         if (!in_lds) {
 #pragma unroll
             for (int k = 0; k < 8; k++) n[k] = wnodes[8u * i + k];
         }
     }
-    // (the staged head is EITHER nodes | escape links OR the top block of the fixed-order walk's nodes OR the wide walk's image)
     // Element e of the fixed-order walk: from LDS when it is in the top block, else from global memory.
     RT_DEV void pnode_pair(uint32_t e, float4 &n0, float4 &n1) const
     {
         const bool in_lds = (head == 2u) & (2u * e < lds_f4); // (the wide walk's fallback for rays with a non-finite 1/d comes here with head == 3)
         const uint32_t k = in_lds ? 2u * e : 0u;
-#if RT_PNODE_GLOBAL_FIRST // A/B: global loads issued before the LDS reads, results selected (8 more v_cndmask, no LDS wait in front of the global loads)
-        float4 g0 = float4{0, 0, 0, 0}, g1 = g0;
-        if (!in_lds) {
-            g0 = pnodes[2u * e];
-            g1 = pnodes[2u * e + 1u];
-        }
-        const float4 l0 = rt_smem[k], l1 = rt_smem[k + 1u];
-        n0 = float4{in_lds ? l0.x : g0.x, in_lds ? l0.y : g0.y, in_lds ? l0.z : g0.z, in_lds ? l0.w : g0.w};
-        n1 = float4{in_lds ? l1.x : g1.x, in_lds ? l1.y : g1.y, in_lds ? l1.z : g1.z, in_lds ? l1.w : g1.w};
-#else
         n0 = rt_smem[k];
         n1 = rt_smem[k + 1u];
         if (!in_lds) {
             n0 = pnodes[2u * e];
             n1 = pnodes[2u * e + 1u];
         }
-#endif
     }
     RT_DEV float4 node(uint32_t i) const { return rt_smem[o_nodes + i]; }
-#if RT_HOT_GLOBAL
-    RT_DEV float4 prim(uint32_t i) const { const bool in_lds = i < n_p_f4; RT_LDS_OR_GLOBAL(in_lds, o_p + i, prims[i]) }
-    // pieces 0 .. N-1 of primitive record `rec` (one decision for the record, not one per piece)
-    template <int N>
-    RT_DEV void prim_rec(uint32_t rec, float4 (&r)[N]) const
-    {
-        const bool in_lds = 4u * rec < n_p_f4;
-        const uint32_t k0 = in_lds ? o_p + 4u * rec : 0u;
-#pragma unroll
-        for (int k = 0; k < N; k++) r[k] = rt_smem[k0 + (uint32_t)k];
-        if (!in_lds) {
-#pragma unroll
-            for (int k = 0; k < N; k++) r[k] = prims[4u * rec + (uint32_t)k];
-        }
-    }
-    RT_DEV float4 trin(uint32_t i) const { const bool in_lds = i < n_t_f4; RT_LDS_OR_GLOBAL(in_lds, o_t + i, tri_normals[i]) }
-    RT_DEV float4 mat(uint32_t i) const { const bool in_lds = i < n_m_f4; RT_LDS_OR_GLOBAL(in_lds, o_m + i, materials[i]) }
-    RT_DEV float4 rec(uint32_t src, uint32_t i) const
-    {
-        const ptrdiff_t ds = fb_spheres - prims, dp = fb_planes - prims; // all three live in one allocation
-        const bool in_lds = (src == SRC_BVH) & (i < n_p_f4);
-        RT_LDS_OR_GLOBAL(in_lds, o_p + i, prims[(src == SRC_FB_SPHERE ? ds : 0) + (src == SRC_FB_PLANE ? dp : 0) + (ptrdiff_t)i])
-    }
-#else // only wide nodes (or the other walks' heads) are staged: records and shading arrays come from global memory
     RT_DEV float4 prim(uint32_t i) const { return prims[i]; }
     template <int N>
     RT_DEV void prim_rec(uint32_t rec, float4 (&r)[N]) const
@@ -271,10 +218,8 @@ struct SceneViewHybrid {
         const ptrdiff_t ds = fb_spheres - prims, dp = fb_planes - prims; // all three live in one allocation
         return prims[(src == SRC_FB_SPHERE ? ds : 0) + (src == SRC_FB_PLANE ? dp : 0) + (ptrdiff_t)i];
     }
-#endif
     RT_DEV float4 flat(uint32_t) const { return float4{0.0f, 0.0f, 0.0f, 0.0f}; } // (the flat traversal needs the whole image in LDS)
     RT_DEV uint32_t esc(uint32_t i) const { return reinterpret_cast<const uint32_t *>(rt_smem + o_esc)[i]; }
-#undef RT_LDS_OR_GLOBAL
 };
 
 // ------------------------------------------------------------------ RNG (shader.wgsl:605-631)
@@ -544,56 +489,21 @@ RT_DEV float environment_pixel_solid_angle(float v, const DevEnv &e) // :739-749
     float sin_t = fmax_(1.0e-6f, rsrt_sinf(theta));
     return e.dphi_dtheta * sin_t; // (d_phi * d_theta) * sin_t
 }
-// Environment gathers (texels, alias entries): 64 MiB of tables read at random, 128 bytes fetched per 16-byte record.
-// RT_ENV_NT: 0 default cache policy | 1 every gather non-temporal | 2 only the alias-slot gather of sample_environment
-// (index = u * N: uniformly random, never reused), the pick-dependent gathers (the few hundred texels of the sun take
-// ~90 % of the picks) stay cacheable.  A/B of what the stream does to the L2 share of the path-state arena.
-#ifndef RT_ENV_NT
-#define RT_ENV_NT 0
-#endif
-#ifndef RT_PNODE_GLOBAL_FIRST
-#define RT_PNODE_GLOBAL_FIRST 0
-#endif
-#ifndef RT_FLAT_BOX_UNROLL
-#define RT_FLAT_BOX_UNROLL 4
-#endif
-#ifndef RT_FLAT_CULL
-#define RT_FLAT_CULL 1 // measured (profiles/r03_fusion_ab.txt): -4.3 .. -5.3 % on the BASELINE frame; see trace_flat
-#endif
-#ifndef RT_FLAT_TRI_PAIR
-#define RT_FLAT_TRI_PAIR 1 // flat traversal: two triangle records per trip of the triangle loop (-1.2 % on the BASELINE frame)
-#endif
-#ifndef RT_TRI_PAIR
-#define RT_TRI_PAIR 1 // fixed-order walk: two triangle records in flight per trip of the leaf loop
-#endif
+// Environment gathers (texels, alias entries): 64 MiB of tables read at random, 128 bytes fetched per 16-byte record, default cache
+// policy (non-temporal gathers were measured in round 2, profiles/r02_l2_sweep.txt: L2 hit rate up, run time +3 .. +10 %)
 typedef float rt_f4v __attribute__((ext_vector_type(4)));
 typedef uint32_t rt_u4v __attribute__((ext_vector_type(4)));
 RT_DEV float4 env_texel(const DevEnv &e, size_t i)
 {
-#if RT_ENV_NT == 1
-    const rt_f4v v = __builtin_nontemporal_load(reinterpret_cast<const rt_f4v *>(e.rgba + i));
-    return float4{v.x, v.y, v.z, v.w};
-#else
     return e.rgba[i];
-#endif
 }
 RT_DEV uint4 env_alias_stream(const DevEnv &e, size_t i) // the uniformly random slot of the alias method
 {
-#if RT_ENV_NT
-    const rt_u4v v = __builtin_nontemporal_load(reinterpret_cast<const rt_u4v *>(e.alias + i));
-    return uint4{v.x, v.y, v.z, v.w};
-#else
     return e.alias[i];
-#endif
 }
 RT_DEV uint4 env_alias(const DevEnv &e, size_t i)
 {
-#if RT_ENV_NT == 1
-    const rt_u4v v = __builtin_nontemporal_load(reinterpret_cast<const rt_u4v *>(e.alias + i));
-    return uint4{v.x, v.y, v.z, v.w};
-#else
     return e.alias[i];
-#endif
 }
 RT_DEV uint32_t clamp_texel(float f, uint32_t n)
 {
@@ -643,9 +553,6 @@ RT_DEV float environment_direction_pmf(const DevEnv &e, float u, float v)
 // alias-table gather of its own: the texel under (u, v) is one of the four the bilinear fetch reads anyway (floor(p) is
 // floor(p - 0.5) or that + 1, and both sides clamp alike); should it ever not be, the gather is still there.  The same copies
 // of the same f32 values, so the bits cannot change; one 128-byte line request less per escape and per aliased NEE pick.
-#ifndef RT_ENV_PACKED
-#define RT_ENV_PACKED 1
-#endif
 RT_DEV EnvBilinearFetch sample_env_bilinear_begin_pmf(const DevEnv &e, float u, float v)
 {
     float x = u * e.wf - 0.5f, y = v * e.hf - 0.5f;
@@ -690,7 +597,7 @@ RT_DEV EnvironmentPick sample_environment_begin(const DevEnv &e, uint32_t &rng) 
     p.entry = env_alias_stream(e, p.index);
     return p;
 }
-// PACKED: the alias target's pmf is read from the entry's pad word instead of the target's own entry (RT_ENV_PACKED; the flat
+// PACKED: the alias target's pmf is read from the entry's pad word instead of the target's own entry (the flat
 // kernel only — the walks have no register left for the fourth word of the entry, tests/test_code_object.py)
 template <bool PACKED = false>
 RT_DEV EnvironmentSample sample_environment_finish(const DevEnv &e, uint32_t &rng, const EnvironmentPick &p) // draws two to four
@@ -1251,7 +1158,7 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
     // hits need no test at all.  Wave-uniform: the group boxes come from the kernel arguments (scalar registers), the skip is a
     // scalar branch.
     uint32_t active = 0xffffffffu;
-    if (RT_FLAT_CULL && coherent && n_leaves != 0u) {
+    if (coherent && n_leaves != 0u) { // (measured, profiles/r03_fusion_ab.txt: -4.3 .. -5.3 % on the BASELINE frame)
         active = sc.cull_always;
         for (uint32_t g = 0; g < sc.n_cull; g++) {
             const float ax = (sc.cull_min[g][0] - o.x) * inv.x, bx = (sc.cull_max[g][0] - o.x) * inv.x;
@@ -1262,9 +1169,9 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
             if (__ballot(!resumed & !(t_0 > t_1)) != 0ull) active |= sc.cull_mask[g];
         }
     }
-#pragma unroll RT_FLAT_BOX_UNROLL // (4: -1.3 % against 1 with the 1024-thread workgroups; it measured the same with 256-thread ones)
+#pragma unroll 4 // ( -1.3 % against 1 with the 1024-thread workgroups; it measured the same with 256-thread ones)
     for (uint32_t L = 0; L < n_leaves; L++) {
-        if (RT_FLAT_CULL && !((active >> L) & 1u)) continue; // (wave-uniform)
+        if (!((active >> L) & 1u)) continue; // (wave-uniform)
         DBG_WAVE_TICK(10);
         DBG_ADD(11, 1);
         const float4 n0 = S.flat(2u * L), n1 = S.flat(2u * L + 1u);
@@ -1292,7 +1199,6 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
     // lanes that entered the loop still hold triangles the wave leaves it; what a lane has not tested goes back to the
     // scheduler in `rem` (every lane has tested at least one triangle by then, so a ray always advances).
     const uint32_t tri_started = (uint32_t)__popcll(__ballot(tri_m != 0ull));
-#if RT_FLAT_TRI_PAIR
     // Two triangles per trip: both records are requested together and the two tests are independent instruction streams
     // until their results are taken in (in record order, so that the any-hit exit sees the same first hit)
     while (tri_m != 0ull) {
@@ -1323,20 +1229,6 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
         if (stop) tri_m = pl_m = sp_m = 0ull;
         if ((uint32_t)__popcll(__ballot(tri_m != 0ull)) * 100u < tri_started * quorum) break; // wave-uniform (quorum 0: never)
     }
-#else
-    while (tri_m != 0ull) {
-        DBG_WAVE_TICK(12);
-        DBG_ADD(13, 1);
-        const uint32_t rec = (uint32_t)__builtin_ctzll(tri_m);
-        tri_m &= tri_m - 1ull;
-        const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u);
-        float u, v;
-        const float t = triangle_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), u, v);
-        RT_FLAT_ACCEPT(t, rec)
-        if (better & anyhit) tri_m = pl_m = sp_m = 0ull;
-        if ((uint32_t)__popcll(__ballot(tri_m != 0ull)) * 100u < tri_started * quorum) break; // wave-uniform (quorum 0: never)
-    }
-#endif
     const unsigned long long tri_left = tri_m; // (the planes and spheres of a ray that is cut short are still tested in this call)
     while (pl_m != 0ull) {
         DBG_WAVE_TICK(15);
@@ -1444,7 +1336,6 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
         }                                                                                                           \
         h.t = better ? (t) : h.t;                                                                                   \
         h.ref = better ? (rec) : h.ref;
-#if RT_TRI_PAIR
         // Two triangles per trip: the walk is bound by the latency of these dependent gathers, not by instruction issue,
         // so both records are requested together and tested one after the other (the order is free: ties go by rank).
         // The same vote ends the triangle loop: lanes hold between none and twenty triangles, and the few with long
@@ -1497,22 +1388,6 @@ RT_DEV void trace_preorder(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
             pl_m &= keep;
             sp_m &= keep;
         }
-#else
-        while (tri_m != 0u) {
-            DBG_WAVE_TICK(12);
-            DBG_ADD(13, 1);
-            const uint32_t p = take_lowest(tri_m);
-            uint32_t base = qi[0];
-#pragma unroll
-            for (int j = 1; j < RT_LEAFQ; j++) base = ((p >> 3) == (uint32_t)j) ? qi[j] : base;
-            const uint32_t rec = base + (p & 7u);
-            const float4 r0 = S.prim(4u * rec), r1 = S.prim(4u * rec + 1u), r2 = S.prim(4u * rec + 2u);
-            float u, v;
-            const float t = triangle_t(o, d, v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z), u, v);
-            RT_PRE_ACCEPT(t, rec)
-            if (better & anyhit) { cur = RT_END; tri_m = pl_m = sp_m = 0u; }
-        }
-#endif
         while (pl_m != 0u) {
             DBG_WAVE_TICK(15);
             DBG_ADD(13, 1);
@@ -1636,23 +1511,18 @@ struct WideRay {
     uint32_t wstride;
     uint32_t win_base, ovf_base, ovf_tri;
     unsigned long long tri_m;
-    // planes and spheres of ONE node (rare inside a mesh's tree, but a ground plane's box is met by most rays): held until the round's
-    // node visits are over and tested then, by all the lanes that hold some, together (RT_WIDE_DEFER_OTHERS)
-    uint32_t oth_base, oth_m, oth_pl;
     RT_DEV void start(V3 o_, V3 d_, V3 inv_, bool anyhit_, const uint32_t *ref_mem_, uint32_t *wmem_, uint32_t wstride_)
     {
         o = o_; d = d_; inv = inv_; anyhit = anyhit_; ref_mem = ref_mem_; wmem = wmem_; wstride = wstride_;
         octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
         win_base = ovf_base = ovf_tri = 0u;
         tri_m = 0ull;
-        oth_base = oth_m = oth_pl = 0u;
     }
     RT_DEV void idle() // a lane without a ray
     {
         w.cur = RT_END; w.grp = 0u;
         win_base = ovf_base = ovf_tri = 0u;
         tri_m = 0ull;
-        oth_base = oth_m = oth_pl = 0u;
         anyhit = false; octant = 0u; ref_mem = nullptr; wmem = nullptr; wstride = 0u;
         o = d = inv = v3(0.0f, 0.0f, 0.0f);
     }
@@ -1670,9 +1540,6 @@ struct WideRay {
     h.t = better ? (t) : h.t;                                                                                       \
     h.ref = better ? (rec) : h.ref;
 
-#ifndef RT_WIDE_DEFER_OTHERS
-#define RT_WIDE_DEFER_OTHERS 0 // 1: the planes / spheres a node visit turns up wait for the end of the round's node visits (0: tested on the spot, lane by lane); measured: 15 k-triangle scene -2 %, suzanne +1 % (profiles/r03_walk_bounds.txt)
-#endif
 // One plane or sphere record of the wide walk (record `rec`; is_plane from the node's type mask)
 #define RT_WIDE_TEST_OTHER(rec, is_plane)                                                                                                             \
     float4 q[4];                                                                                                                                         \
@@ -1715,10 +1582,9 @@ RT_DEV void wide_nodes(DBG_DECL const View &S, const DevScene &sc, WideRay &r, H
         const uint32_t rec_base = as_u(n[1].w), tri32 = as_u(n[2].w), pl32 = as_u(n[3].w);
         steps += (uint32_t)__popc(lm);
         bool stop = false;
-        // planes and spheres (rare inside a mesh's tree): the first node's that turns some up are held for wide_others; should a second
-        // node bring more while those wait, these are tested here and now, one at a time
+        // planes and spheres (rare inside a mesh's tree): tested here and now, one at a time (held to the end of the round's node visits and
+        // tested together: 15 k-triangle scene -2 %, suzanne +1 %, profiles/r03_walk_bounds.txt — not kept)
         uint32_t oth = lm & ~tri32;
-        if (RT_WIDE_DEFER_OTHERS && oth != 0u && r.oth_m == 0u) { r.oth_base = rec_base; r.oth_m = oth; r.oth_pl = pl32; oth = 0u; }
         while (oth != 0u) {
             DBG_WAVE_TICK(15);
             DBG_ADD(13, 1);
@@ -1747,17 +1613,8 @@ RT_DEV void wide_nodes(DBG_DECL const View &S, const DevScene &sc, WideRay &r, H
         } else {
             w.cur = RT_END;
         }
-        if (stop) { w.cur = RT_END; r.tri_m = 0ull; r.ovf_tri = 0u; r.oth_m = 0u; }
+        if (stop) { w.cur = RT_END; r.tri_m = 0ull; r.ovf_tri = 0u; }
         if ((uint32_t)__popcll(__ballot(r.looking())) * 100u < n_started * quorum) break; // wave-uniform
-    }
-    // the planes / spheres held: every lane that holds some tests them now, a record per trip (all of them: nothing of this kind is carried
-    // out of a round)
-    while (r.oth_m != 0u) {
-        DBG_WAVE_TICK(15);
-        DBG_ADD(13, 1);
-        const uint32_t p = take_lowest(r.oth_m);
-        RT_WIDE_TEST_OTHER(r.oth_base + p, (r.oth_pl >> p) & 1u)
-        if (better & r.anyhit) { w.cur = RT_END; r.tri_m = 0ull; r.ovf_tri = 0u; r.oth_m = 0u; }
     }
 }
 

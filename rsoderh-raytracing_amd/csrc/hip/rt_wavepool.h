@@ -48,30 +48,17 @@ enum CtBits : uint32_t {
     CT_FLAGS = 120u,
     CT_SHIFT = 7u
 };
-#ifndef RT_RNG_HOT
-#define RT_RNG_HOT 1 // flat traversal: the RNG word travels in the H_T cell instead of a cold column (see the kernel)
-#endif
-#ifndef RT_GEN_TRACE
-#define RT_GEN_TRACE 1 // GEN traces the camera rays it builds (a first round of them, for the walks) instead of queueing them for TRACE
-#endif
-#ifndef RT_FLAT_VOTE
-#define RT_FLAT_VOTE 1 // flat traversal: a wave vote may end the triangle loop, the rays cut short are re-queued (needs RT_RNG_HOT, RT_COLD_COMPACT)
-#endif
 enum ColdField {
     C_TX, C_TY, C_TZ, C_LX, C_LY, C_LZ, C_NEEX, C_NEEY, C_NEEZ, C_LASTPDF, C_OUT,
-    C_RNG, // (the flat traversal keeps it in a hot cell when RT_RNG_HOT)
+    C_RNG, // (the flat traversal keeps it in a hot cell)
     C_BOUNCE,
     C_REF, // tree-walk traversals only: best hit of the extension ray, record | source << 30
     C_COUNT,
     // the flat traversal stops early: its bounce count and hit record ride in the idle cursor bits of H_CT; two columns
-    // hold the untested triangles of a ray whose triangle loop was cut short (RT_FLAT_VOTE; only such rays touch them)
+    // hold the untested triangles of a ray whose triangle loop was cut short (only such rays touch them)
     C_REM_LO = C_RNG, C_REM_HI = C_BOUNCE,
-    C_COUNT_FLAT = RT_RNG_HOT ? (RT_FLAT_VOTE ? C_REF : C_RNG) : C_BOUNCE
+    C_COUNT_FLAT = C_REF
 };
-// RT_COLD_COMPACT=0 restores 14 cold columns for every traversal (A/B of the arena's L2 footprint)
-#ifndef RT_COLD_COMPACT
-#define RT_COLD_COMPACT 1
-#endif
 #define RT_FLAT_BOUNCE_SHIFT 8u     // flat traversal, H_CT payload: hit record (6-bit index | 2-bit source) | bounce << 8 | resumed << 24
 #define RT_FLAT_BOUNCE_BITS 0xffff00u
 #define RT_FLAT_RESUMED (1u << 24)
@@ -83,46 +70,23 @@ enum ColdField {
 #define C_COUNT_WIDE_DEEP ((uint32_t)C_COUNT + RT_WSTATE_WORDS) /* TRAV 5: + overflow count and overflow words */
 __host__ __device__ constexpr uint32_t pool_cold_columns(int trav)
 {
-    return (RT_COLD_COMPACT && trav == 2) ? (uint32_t)C_COUNT_FLAT : (trav == 4 ? C_COUNT_WIDE : (trav == 5 ? C_COUNT_WIDE_DEEP : (uint32_t)C_COUNT));
+    return trav == 2 ? (uint32_t)C_COUNT_FLAT : (trav == 4 ? C_COUNT_WIDE : (trav == 5 ? C_COUNT_WIDE_DEEP : (uint32_t)C_COUNT));
 }
-enum PoolTag { TAG_FREE = 0, TAG_TRACE = 1, TAG_MISS = 2, TAG_SHADE = 3, TAG_FINISH = 4, TAG_PRIM = 5, TAG_IDLE = 6 };
-// ST_PRIM (flat traversal with RT_FLAT_PRIM_STAGE only): rays whose triangle loop was cut short, scheduled apart from fresh
-// rays so that a batch of them skips the box loop; it runs TRACE's code
-enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_FINISH = 4, ST_PRIM = 5, ST_MAX = 6 };
-#ifndef RT_FLAT_PRIM_STAGE
-#define RT_FLAT_PRIM_STAGE 0 // measured: 28.2 ms per 64 spp at its best quorum (40-50) against 28.0 ms without it at quorum 20; the sixth stage costs the census 1 %
-#endif
+enum PoolTag { TAG_FREE = 0, TAG_TRACE = 1, TAG_MISS = 2, TAG_SHADE = 3, TAG_FINISH = 4, TAG_IDLE = 6 };
+enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_FINISH = 4, ST_COUNT = 5 };
 
-// RT_HOT_GLOBAL (experiment, default 0 in rt_device.h): the walk kernels (hybrid scene view, SV 2) keep only the TAG column of the hot state in
-// LDS; the other ten hot columns follow the cold ones in the wave's global arena, and what a ray gathers per lane — wide nodes, primitive
-// records, normals, materials — takes the 120 KB of LDS they held (rsrt_api.hip, wide_image).  The idea: the vector memory path is busy
-// 93-97 % of the cycles in these kernels, and a wave's state column is 768 contiguous bytes while the scene reads are per-lane gathers.
-// Measured: NOT faster (suzanne +9 %, 15 k-triangle scene +-0): a column read by 64 scattered slots still costs the path ~30 tag
-// lookups (it coalesces per quad of lanes, not per line), and every stage now starts with an L2 round trip.
-// RT_WIDE_REFILL: the wide walk's TRACE stage takes a LIST of waiting rays longer than the wave — a lane whose ray is done takes the next one
-// between two rounds — and the scheduler lets such lists build up (see "2. which stage" in the kernel).  Why: rays need 3-25 node visits,
-// and with one ray per lane and stage call the node and triangle loops ran at 54-61 % of the lanes (profiles/r03_wide_walk.txt).
-#ifndef RT_WIDE_REFILL
-#define RT_WIDE_REFILL 0
-#endif
-#ifndef RT_SCALAR_WAVE
-#define RT_SCALAR_WAVE 0 // 1: every pool kernel is told that its wave index is wave-uniform (scalar LDS / arena bases), and SHADE writes through an opaque copy of the slot index
-#endif
-#ifndef RT_REFILL_LIST
-#define RT_REFILL_LIST 128u // entries of the compaction list of the kernels that refill (the others: 64, one per lane)
-#endif
-__host__ __device__ constexpr uint32_t pool_list_dwords(int trav) { return (RT_WIDE_REFILL && trav >= 4) ? (uint32_t)RT_REFILL_LIST : 64u; }
-template <uint32_t POOL, int TRAV, bool HOTG>
+__host__ __device__ constexpr uint32_t pool_list_dwords(int) { return 64u; } // the compaction list: one entry per lane
+template <uint32_t POOL, int TRAV>
 struct PoolLayout {
     static constexpr uint32_t kSlotsPerLane = (POOL + 63u) / 64u;
-    static constexpr uint32_t kHotDwords = (HOTG ? 1u : (uint32_t)H_COUNT) * POOL; // in LDS: every hot column, or the tag column alone
+    static constexpr uint32_t kHotDwords = (uint32_t)H_COUNT * POOL; // in LDS: every hot column
     static constexpr uint32_t kListDwords = pool_list_dwords(TRAV);
     static constexpr uint32_t kWaveLdsDwords = kHotDwords + kListDwords;
     static constexpr uint32_t kColdColumns = pool_cold_columns(TRAV);
-    static constexpr uint32_t kWaveColdDwords = (kColdColumns + (HOTG ? (uint32_t)H_CT : 0u)) * POOL; // (H_CT = the number of hot columns before the tag)
+    static constexpr uint32_t kWaveColdDwords = kColdColumns * POOL;
 };
 
-RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE, MISS, SHADE, FINISH, PRIM; IDLE -> none
+RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE, MISS, SHADE, FINISH; IDLE -> none
 
 // The lanes of a wave hand data to each other through memory: the compaction list, the hot columns and the stage tag
 // (LDS) and the cold columns (global memory) are written by the lane that runs a stage and read by whichever lane
@@ -137,27 +101,11 @@ RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE
     } while (0)
 
 // A finished path's radiance goes to the sample buffer once and is read once, by rt_resolve_kernel, long after: a
-// write-once stream that has no business occupying L2 lines the path-state arena wants.
-//   RT_SAMPLE_STORE  0 three plain dword stores | 1 one plain 12-byte store | 2 one non-temporal 12-byte store |
-//                    3 one write-through 12-byte store whose line is dropped from L2 (sc1)
-#ifndef RT_SAMPLE_STORE
-#define RT_SAMPLE_STORE 2
-#endif
+// write-once stream that has no business occupying L2 lines the path-state arena wants — one non-temporal 12-byte store
+// (three dword stores, a plain 12-byte store and an sc1 write-through were measured against it: profiles/r02_l2_sweep.txt)
 typedef float rt_f3v __attribute__((ext_vector_type(3)));
 typedef rt_f3v rt_f3v_a4 __attribute__((aligned(4)));
-RT_DEV void store_sample(float *dst, V3 L)
-{
-#if RT_SAMPLE_STORE == 0
-    dst[0] = L.x; dst[1] = L.y; dst[2] = L.z;
-#elif RT_SAMPLE_STORE == 1
-    *reinterpret_cast<rt_f3v_a4 *>(dst) = rt_f3v{L.x, L.y, L.z};
-#elif RT_SAMPLE_STORE == 2
-    __builtin_nontemporal_store(rt_f3v{L.x, L.y, L.z}, reinterpret_cast<rt_f3v_a4 *>(dst));
-#else
-    const rt_f3v v = {L.x, L.y, L.z};
-    asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
-#endif
-}
+RT_DEV void store_sample(float *dst, V3 L) { __builtin_nontemporal_store(rt_f3v{L.x, L.y, L.z}, reinterpret_cast<rt_f3v_a4 *>(dst)); }
 
 #ifndef RT_POOL_WAVES_PER_SIMD
 #define RT_POOL_WAVES_PER_SIMD 4
@@ -177,47 +125,39 @@ template <> struct PoolView<2> { typedef SceneViewHybrid type; static __device__
 template <int SV, uint32_t BLOCK, uint32_t POOL, int TRAV>
 __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
 {
-    constexpr bool kHotG = RT_HOT_GLOBAL != 0 && SV == 2; // hot columns (all but the tag) in the global arena
-    typedef PoolLayout<POOL, TRAV, kHotG> L;
+    typedef PoolLayout<POOL, TRAV> L;
     constexpr bool kBounceInCt = pool_cold_columns(TRAV) == (uint32_t)C_COUNT_FLAT; // no C_BOUNCE / C_REF column
     // Flat traversal: a ray finishes in one TRACE call — or is cut short by the triangle-loop vote with its best t parked where the
     // result would go — so "best t so far" is INFINITY at every fresh start and the H_T cell is
     // only needed for the RESULT of the extension ray — which fits the shadow direction's first cell, dead by then (the
     // shadow ray is traced first).  H_T then carries the RNG word instead of a cold column: SHADE's first dependent memory
     // access, the alias-table gather, can leave with the cold loads instead of a memory round trip after them.
-    constexpr bool kRngHot = RT_RNG_HOT && TRAV == 2;
+    constexpr bool kRngHot = TRAV == 2;
     constexpr uint32_t kTCell = kRngHot ? (uint32_t)H_SX : (uint32_t)H_T; // where the extension ray's t waits for SHADE / MISS
-    constexpr bool kFlatVote = RT_FLAT_VOTE && kRngHot && kBounceInCt; // a TRACE call may return a flat traversal unfinished
-    constexpr bool kPackedMiss = RT_ENV_PACKED != 0 && TRAV == 2; // MISS reads an escaping ray's pmf from the texels' alpha (rt_device.h)
-    constexpr bool kRefill = RT_WIDE_REFILL != 0 && TRAV >= 4;
-    constexpr bool kDeep = TRAV == 5; // wide walk of a tree deeper than its register stack // TRACE refills its lanes from a list longer than the wave
-    constexpr bool kGenTrace = RT_GEN_TRACE != 0 && TRAV >= 2; // GEN traces the camera ray it has built (the near-first tree walks, kept for RSRT_FLAG_PRUNE, would spill)
-    constexpr uint32_t ST_COUNT = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)ST_MAX : (uint32_t)ST_PRIM;
-    constexpr uint32_t kTagCut = (kFlatVote && RT_FLAT_PRIM_STAGE) ? (uint32_t)TAG_PRIM : (uint32_t)TAG_TRACE;
+    constexpr bool kFlatVote = kRngHot && kBounceInCt; // a TRACE call may return a flat traversal unfinished
+    constexpr bool kPackedMiss = TRAV == 2; // MISS reads an escaping ray's pmf from the texels' alpha (rt_device.h)
+    constexpr bool kGenTrace = TRAV >= 2; // GEN traces the camera ray it has built (the near-first tree walks, kept for RSRT_FLAG_PRUNE, would spill)
     const DevScene &sc = P.scene;
     if (SV != 0) stage_scene_lds(sc);
     const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     // (readfirstlane: the compiler cannot know that threadIdx.x / 64 is wave-uniform; told so, the wave's LDS and arena bases live in scalar
     // registers and a column access is base + 32-bit lane offset instead of a 64-bit address per lane)
-    // (RT_SCALAR_WAVE 0: only the walk kernels — the flat kernel, which already holds its cull boxes in scalar registers, runs out of them)
-    constexpr bool kScalarWave = SV == 2 || RT_SCALAR_WAVE != 0;
+    // (only the walk kernels — the flat kernel, which already holds its cull boxes in scalar registers, runs out of them: +1-1.5 %)
+    constexpr bool kScalarWave = SV == 2;
     const uint32_t wave = kScalarWave ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / RT_WAVE)) : threadIdx.x / RT_WAVE;
     uint32_t *const lds32 = reinterpret_cast<uint32_t *>(rt_smem + sc.lds_float4s);
-    uint32_t *const W = lds32 + wave * L::kWaveLdsDwords; // this wave's hot columns (kHotG: its tag column)
-    uint32_t *const WCT = W + (kHotG ? 0u : (uint32_t)H_CT * POOL); // the tag column: always LDS (the census reads all of it every trip)
+    uint32_t *const W = lds32 + wave * L::kWaveLdsDwords; // this wave's hot columns
+    uint32_t *const WCT = W + (uint32_t)H_CT * POOL; // the tag column (the census reads all of it every trip)
     uint32_t *const list = W + L::kHotDwords;
     uint32_t *const G = P.cold_state + (size_t)(blockIdx.x * (BLOCK / RT_WAVE) + wave) * L::kWaveColdDwords; // cold columns
-    uint32_t *const GH = G + L::kColdColumns * POOL; // kHotG: the hot columns H_OX .. H_T, behind the cold ones
     const bool prune = (P.flags & RSRT_FLAG_PRUNE) != 0;
     const bool anyhit_shadow = !(P.flags & RSRT_FLAG_REFERENCE_TRAVERSAL);
     const uint32_t tile_px = P.tile_w * P.tile_h;
 
-    // (kHotG is a constant: each of these is ONE load or store, from the arena or from LDS — never a select between two pointers,
-    // which would compile to flat loads)
-#define HOT(f, slot) (kHotG ? GH[(f) * POOL + (slot)] : W[(f) * POOL + (slot)])           /* a hot column other than the tag, as u32 */
+#define HOT(f, slot) W[(f) * POOL + (slot)]           /* a hot column other than the tag, as u32 */
 #define HOTF(f, slot) as_f(HOT(f, slot))
-#define SETHU(f, slot, val) do { if (kHotG) GH[(f) * POOL + (slot)] = (val); else W[(f) * POOL + (slot)] = (val); } while (0)
+#define SETHU(f, slot, val) W[(f) * POOL + (slot)] = (val)
 #define SETH(f, slot, val) SETHU(f, slot, as_u(val))
 #define CT_OF(slot) WCT[(slot)]
 #define TAG_OF(slot) (WCT[(slot)] & 7u)
@@ -262,7 +202,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             COLD(C_REM_LO, slot) = (uint32_t)flat_rem;
             COLD(C_REM_HI, slot) = (uint32_t)(flat_rem >> 32);
             if (!shadow) SETH(kTCell, slot, h.t);
-            SET_CT(slot, RT_FLAT_RESUMED | bounce_bits | (shadow ? 0u : h.ref), ct & CT_FLAGS, kTagCut);
+            SET_CT(slot, RT_FLAT_RESUMED | bounce_bits | (shadow ? 0u : h.ref), ct & CT_FLAGS, TAG_TRACE);
         } else if (!done) { // to be resumed: best t and cursor
             if (!kRngHot) SETH(H_T, slot, h.t);
             if (TRAV != 2 && !shadow && found) COLD(C_REF, slot) = h.ref;
@@ -281,7 +221,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         }
     };
     // One ray of `slot` (tag / flags word `ct`) from o along d, traced or resumed, and what the slot is left as: TRACE's body, as a
-    // lambda because GEN runs it too (RT_GEN_TRACE: a new path's camera ray is traced by the lanes that have just built it).
+    // lambda because GEN runs it too (a new path's camera ray is traced by the lanes that have just built it).
     auto trace_slot = [&](const uint32_t slot, const uint32_t ct, const V3 o, const V3 d, const bool coherent) __attribute__((always_inline)) {
         const bool shadow = (ct & F_SHADOW) != 0u;
         // resume (or start: cur = root, best = INFINITY) the traversal
@@ -316,13 +256,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         // ---------------- 2. which stage: the fullest (ties: the later stage, which drains paths)
         uint32_t best = ST_COUNT, best_n = 0;
         for (uint32_t s = 0; s < ST_COUNT; s++)
-            if (count[s] >= best_n && count[s] > 0 && !(kRefill && s == ST_TRACE)) { best = s; best_n = count[s]; }
-        if (kRefill) {
-            // ... but a TRACE that refills its lanes wants a LONG list: the other stages run while one of them can fill the wave, TRACE once
-            // P.refill_min rays wait for it, and short of both whichever is nearer its mark
-            const uint32_t tn = count[ST_TRACE];
-            if (tn > 0u && (best == ST_COUNT || (best_n < 64u && (tn >= P.refill_min || tn * 64u > best_n * P.refill_min)))) { best = ST_TRACE; best_n = tn; }
-        }
+            if (count[s] >= best_n && count[s] > 0) { best = s; best_n = count[s]; }
         if (best == ST_COUNT) break; // nothing left anywhere
         // ---------------- 3. compaction: dense list of the chosen stage's slots
         uint32_t base = 0;
@@ -337,9 +271,9 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         const uint32_t n_run = min(best_n, 64u);
         const bool on = lane < n_run;
         const uint32_t slot = on ? list[lane] : 0u;
-        const uint32_t dbg_stage = best == ST_PRIM ? (uint32_t)ST_TRACE : best; // (the diagnostic counters file PRIM under TRACE)
+        const uint32_t dbg_stage = best;
         (void)dbg_stage;
-        if (lane == 0) { DBG_ADD(dbg_stage, 1); DBG_ADD(5 + dbg_stage, (kRefill && best == ST_TRACE) ? min(best_n, L::kListDwords) : n_run); }
+        if (lane == 0) { DBG_ADD(dbg_stage, 1); DBG_ADD(5 + dbg_stage, n_run); }
         DBG_STAMP(22); // census + compaction
 
         if (best == ST_GEN) {
@@ -400,88 +334,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
                     if (lane + 64u * k < POOL && TAG_OF(lane + 64u * k) == TAG_FREE) SET_TAG(lane + 64u * k, TAG_IDLE);
             }
-        } else if (kRefill && best == ST_TRACE) {
-            // ---------------- TRACE with refill (wide walk): the list holds up to kListDwords waiting rays; lanes take them in list order, and a
-            // lane whose ray is done takes the next one between two rounds.  Once the list is used up and fewer than P.stop_quorum percent of
-            // the lanes still hold a ray, what is held is tested and the unfinished rays park their stacks (cold columns) for the next TRACE.
-            // A ray's arithmetic is what it is in any other schedule: which lane runs it, and beside whom, changes nothing.
-            if constexpr (kRefill) {
-                const uint32_t n_list = min(best_n, L::kListDwords), n_ref = min(n_list, 64u);
-                uint32_t next = 0u, steps = 0u;
-                bool have = false;   // this lane holds a ray of the wide walk
-                bool axial = false;  // this lane holds a ray with a non-finite 1/d: it waits for the fixed-order walk behind the loop
-                uint32_t my_slot = 0u, my_ct = 0u;
-                float my_t_in = 0.0f;
-                WideRay r;
-                Hit h;
-                r.idle();
-                r.w.fresh(); r.w.cur = RT_END;
-                h.t = RT_INFINITY; h.ref = 0u; h.src = SRC_BVH; h.u = h.v = 0.0f;
-                for (;;) {
-                    // free lanes take the next slots of the list
-                    if (next < n_list) {
-                        const unsigned long long want = __ballot(!have & !axial);
-                        const uint32_t idx = next + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
-                        if (!have && !axial && idx < n_list) {
-                            const uint32_t s = list[idx];
-                            const uint32_t ct = CT_OF(s);
-                            const bool shadow = (ct & F_SHADOW) != 0u;
-                            const uint32_t dcol = shadow ? (uint32_t)H_SX : (uint32_t)H_EX;
-                            const V3 o = v3(HOTF(H_OX, s), HOTF(H_OY, s), HOTF(H_OZ, s));
-                            const V3 d = v3(HOTF(dcol, s), HOTF(dcol + 1u, s), HOTF(dcol + 2u, s));
-                            h.t = HOTF(H_T, s);
-                            h.ref = shadow ? 0u : RT_REF_UNKNOWN; // (an earlier call's best record stays in its cold column unless beaten, see trace_slot)
-                            my_slot = s; my_ct = ct; my_t_in = h.t;
-                            const V3 inv = rt_rcp3(d);
-                            const float finite = ((inv.x + inv.y) + inv.z) * 0.0f + ((o.x + o.y) + o.z) * 0.0f; // (as in trace_dispatch)
-                            if (finite == 0.0f) {
-                                r.start(o, d, inv, shadow && anyhit_shadow, &COLD(C_REF, s), &G[C_WIDE_STATE * POOL + s], POOL);
-                                if ((ct >> CT_SHIFT) != 0u) wstate_load<kDeep>(r.w, r.wmem, POOL); // parked by an earlier call
-                                else r.w.fresh();
-                                have = true;
-                            } else { // a non-finite 1/d (axis-parallel rays: next to none): the fixed-order walk, behind the loop; the lane sits out
-                                axial = true;
-                            }
-                        }
-                        next = min(n_list, next + (uint32_t)__popcll(want));
-                    }
-                    const uint32_t n_have = (uint32_t)__popcll(__ballot(have));
-                    if (n_have == 0u) { if (next >= n_list) break; continue; }
-                    DBG_WAVE_TICK(14);
-                    wide_nodes<kDeep>(DBG_ARG S, sc, r, h, P.descend_quorum, n_have, steps);
-                    wide_tris(DBG_ARG S, sc, r, h, P.descend_quorum, false);
-                    if (have && r.done()) { // this ray is through: the lane is free for the next
-                        ray_end(my_slot, my_ct, h, RT_END, my_t_in, 0ull);
-                        have = false;
-                        r.idle();
-                    }
-                    if (next >= n_list) {
-                        const uint32_t n_act = (uint32_t)__popcll(__ballot(have));
-                        if (n_act == 0u) break;
-                        if (n_act * 100u < n_ref * P.stop_quorum) { // the wave stops here
-                            while (__ballot(r.holds()) != 0ull) wide_tris(DBG_ARG S, sc, r, h, P.descend_quorum, true);
-                            if (have) {
-                                if (r.w.cur != RT_END) wstate_store<kDeep>(r.w, &G[C_WIDE_STATE * POOL + my_slot], POOL);
-                                ray_end(my_slot, my_ct, h, r.w.cur == RT_END ? RT_END : 1u, my_t_in, 0ull);
-                            }
-                            break;
-                        }
-                    }
-                }
-                n_work += steps;
-                if (axial) { // (its slot's columns are as they were: read again, walk to the end)
-                    const bool shadow = (my_ct & F_SHADOW) != 0u;
-                    const uint32_t dcol = shadow ? (uint32_t)H_SX : (uint32_t)H_EX;
-                    const V3 o = v3(HOTF(H_OX, my_slot), HOTF(H_OY, my_slot), HOTF(H_OZ, my_slot));
-                    const V3 d = v3(HOTF(dcol, my_slot), HOTF(dcol + 1u, my_slot), HOTF(dcol + 2u, my_slot));
-                    Hit ha;
-                    ha.t = HOTF(H_T, my_slot); ha.ref = shadow ? 0u : RT_REF_UNKNOWN; ha.src = SRC_BVH; ha.u = ha.v = 0.0f;
-                    uint32_t cur = my_ct >> CT_SHIFT;
-                    trace_preorder(DBG_ARG S, sc, o, d, prune, shadow && anyhit_shadow, 0xffffffffu, 0u, cur, ha, &COLD(C_REF, my_slot), n_work);
-                    ray_end(my_slot, my_ct, ha, RT_END, ha.t, 0ull);
-                }
-            }
-        } else if (best == ST_TRACE || best == ST_PRIM) {
+        } else if (best == ST_TRACE) {
             // ---------------- TRACE: one ray of the slot from its vertex O — the shadow ray (direction S, any
             // hit) while one is pending, else the extension ray (direction E, closest hit): cast_ray_bvh
             if (on) {
@@ -581,7 +434,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     surf = resolve_hit(S, h, o, d);
                     mat = load_material(S, surf.material_id);
                     SHADE_STAMP(11);
-                    es = sample_environment_finish<RT_ENV_PACKED != 0>(P.env, rng, pick);
+                    es = sample_environment_finish<true>(P.env, rng, pick);
                     SHADE_STAMP(12);
                     // the previous vertex's NEE term, lit: :1246-1249 of the previous iteration
                     if ((ct & (F_NEE | F_OCCLUDED)) == F_NEE) Lr = Lr + nee_prev;
@@ -633,12 +486,6 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     store_sample(P.sample_buf + (size_t)COLD(C_OUT, slot) * 3u, Lr);
                     SET_TAG(slot, TAG_FREE);
                 } else {
-                    // (kHotG: the columns read at the top of the stage are written here; an opaque copy of the slot index keeps the compiler
-                    // from carrying their 64-bit addresses through the whole stage — they spilled)
-                    const uint32_t slot_r = slot;
-                    uint32_t slot_w = slot_r;
-                    if (kHotG || RT_SCALAR_WAVE != 0) asm volatile("" : "+v"(slot_w));
-#define slot slot_w
                     SETC(C_LX, slot, Lr.x); SETC(C_LY, slot, Lr.y); SETC(C_LZ, slot, Lr.z);
                     if (nee_counts) { SETC(C_NEEX, slot, nee.x); SETC(C_NEEY, slot, nee.y); SETC(C_NEEZ, slot, nee.z); }
                     if (!finished) {
@@ -653,7 +500,6 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     if (!kRngHot) SETH(H_T, slot, RT_INFINITY);
                     SET_CT(slot, kBounceInCt ? (bounce << RT_FLAT_BOUNCE_SHIFT) : 0u,
                            (want_shadow ? (uint32_t)F_SHADOW : 0u) | (finished ? 0u : (uint32_t)F_EXT) | (nee_counts ? (uint32_t)F_NEE : 0u), TAG_TRACE);
-#undef slot
                 }
             }
         } else {
