@@ -54,6 +54,7 @@ struct RenderParams {
     uint32_t chunk_px, n_subtiles; // a chunk covers chunk_px consecutive pixels of a tile (tile_px / n_subtiles)
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
     uint32_t trace_budget, descend_quorum, flat_quorum, stop_quorum;
+    uint32_t coop_lds_cap, coop_narrow_at; // cooperative walk (rt_coop.h): node-stack entries kept in LDS, outstanding items at which a wave pops one item a trip
     uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
     float *sample_buf;
     unsigned int *work_counter;
@@ -317,6 +318,9 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
 // LDS of the 1024-thread walk kernels (hybrid scene view): sixteen waves' pools and beside them the traversal's part of the scene
 static constexpr size_t kHybridPoolBytes = (size_t)(1024 / RT_WAVE) * 4u * ((size_t)H_COUNT * RT_WALK_POOL + pool_list_dwords(4));
 static constexpr uint32_t kHybridRoomF4 = (uint32_t)((160 * 1024 - kHybridPoolBytes) / sizeof(float4));
+// ... and of the cooperative walk's kernel (TRAV 6): 128-slot pools with their two work stacks
+#define RT_COOP_POOL 128u
+static constexpr uint32_t kCoopRoomF4 = (uint32_t)((160 * 1024 - (size_t)(1024 / RT_WAVE) * 4u * pool_wave_lds_dwords(6, RT_COOP_POOL)) / sizeof(float4));
 #include "rt_alias_device.h"
 #include "rt_bvh_device.h"
 
@@ -383,6 +387,80 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
         }
         if (h.did_hit()) hit_barycentrics(S, h, o, d); // as SHADE does: the traversals do not carry u, v
     }
+    if ((mode & 1u) == 0 && !h.did_hit()) { // cast_ray's brute-force fallback (the MISS stage)
+        for (uint32_t k = 0; k < sc.n_spheres; k++) {
+            float u, v;
+            float t = test_record(S, k, SRC_FB_SPHERE, o, d, u, v);
+            if (t >= 0.0f && t < h.t) { h.t = t; h.ref = k; h.src = SRC_FB_SPHERE; }
+        }
+        for (uint32_t k = 0; k < sc.n_planes; k++) {
+            float u, v;
+            float t = test_record(S, k, SRC_FB_PLANE, o, d, u, v);
+            if (t >= 0.0f && t < h.t) { h.t = t; h.ref = k; h.src = SRC_FB_PLANE; }
+        }
+    }
+    rsrt_hit r;
+    memset(&r, 0, sizeof r);
+    if (h.did_hit()) {
+        Surface s = resolve_hit(S, h, o, d);
+        r.did_hit = 1;
+        r.distance = h.t;
+        r.hit_point[0] = s.point.x; r.hit_point[1] = s.point.y; r.hit_point[2] = s.point.z;
+        r.normal[0] = s.normal.x; r.normal[1] = s.normal.y; r.normal[2] = s.normal.z;
+        r.material_id = s.material_id;
+    } else if ((mode & 1u) == 0) {
+        r.distance = RT_INFINITY; // cast_ray returns its `result` initialiser on a total miss (shader.wgsl:568-574, :600)
+    }
+    out[i] = r;
+}
+
+// The ray-query probe of the cooperative walk (TRAV 6, rt_coop.h): a wave takes 64 rays into a one-column "pool" of its own (slot = lane) and runs
+// the very functions the production kernel's TRACE stage runs — coop_push_rays, coop_trace, coop_slow_rays.  gstack: RT_COOP_GCAP dwords a wave.
+template <int SV>
+__global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_coop_kernel(DevScene sc, uint32_t n, const float *origins, const float *dirs,
+                                                                     uint32_t mode, uint32_t flags, uint32_t repeat, rsrt_hit *out, uint32_t *gstack,
+                                                                     uint32_t lds_cap, uint32_t narrow_at)
+{
+    if (SV != 0) stage_scene_lds(sc);
+    const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
+    constexpr uint32_t kPool = 64u;
+    typedef CoopCols<kPool> C;
+    const uint32_t lane = threadIdx.x & (RT_WAVE - 1u);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / RT_WAVE));
+    uint32_t *const W = reinterpret_cast<uint32_t *>(rt_smem + sc.lds_float4s) + wave * pool_wave_lds_dwords(6, kPool);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    const V3 o = valid ? v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]) : v3(0.0f, 0.0f, 0.0f);
+    const V3 d = valid ? v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]) : v3(0.0f, 0.0f, 1.0f);
+#ifdef RT_INSTRUMENT
+    DbgCounters dbg;
+#endif
+    Hit h;
+    h.t = RT_INFINITY; h.ref = 0; h.src = SRC_BVH; h.u = h.v = 0.0f;
+    uint32_t work = 0;
+    for (uint32_t k = 0; k < repeat; k++) { // (RSRT_PROBE_REPEAT: the same queries again; the result does not change)
+        W[C::O + lane] = as_u(o.x); W[C::O + kPool + lane] = as_u(o.y); W[C::O + 2u * kPool + lane] = as_u(o.z);
+        W[C::E + lane] = as_u(d.x); W[C::E + kPool + lane] = as_u(d.y); W[C::E + 2u * kPool + lane] = as_u(d.z);
+        W[C::S + lane] = 0u; W[C::S + kPool + lane] = 0u; W[C::S + 2u * kPool + lane] = 0u;
+        W[C::CT + lane] = (uint32_t)F_EXT | (uint32_t)TAG_TRACE;
+        RT_WAVE_HANDOVER();
+        CoopStacks cs;
+        cs.ls = W + C::DWORDS; cs.ns = cs.ls + RT_COOP_LCAP;
+        cs.gs = gstack + (size_t)(blockIdx.x * (RT_BLOCK / RT_WAVE) + wave) * RT_COOP_GCAP;
+        cs.ns_n = cs.ls_n = cs.gs_n = 0u;
+        cs.lds_cap = lds_cap; cs.narrow_at = narrow_at;
+        coop_push_rays<kPool>(W, cs, valid, lane, W[C::CT + lane], (uint32_t)F_EXT, (uint32_t)F_SHADOW);
+        coop_trace<kPool>(DBG_ARG S, W, cs, false, lane, work);
+        RT_WAVE_HANDOVER();
+        const bool mine[1] = {valid};
+        const uint32_t slots[1] = {lane};
+        coop_slow_rays<kPool, 1u>(DBG_ARG S, sc, W, mine, slots, false, work);
+        h.t = as_f(W[C::BEST + 2u * lane + 1u]);
+        h.ref = W[C::BEST + 2u * lane];
+        RT_WAVE_HANDOVER();
+    }
+    if (!valid) return; // (nothing wave-wide from here on)
+    if (h.did_hit()) hit_barycentrics(S, h, o, d); // as SHADE does: the traversals do not carry u, v
     if ((mode & 1u) == 0 && !h.did_hit()) { // cast_ray's brute-force fallback (the MISS stage)
         for (uint32_t k = 0; k < sc.n_spheres; k++) {
             float u, v;
@@ -522,6 +600,9 @@ static const void *pool_function(int trav)
 static const void *variant_function(int kv, int sv, int trav)
 {
     if (kv == 0) return sv == 1 ? reinterpret_cast<const void *>(&rt_render_kernel<true>) : reinterpret_cast<const void *>(&rt_render_kernel<false>);
+    if (trav == 6) // the cooperative walk: 128-slot pools; one 1024-thread workgroup per CU beside the staged node prefix, else 256-thread workgroups
+        return sv == 2 ? reinterpret_cast<const void *>(&rt_render_pool_kernel<2, 1024, RT_COOP_POOL, 6>)
+                       : (sv == 1 ? reinterpret_cast<const void *>(&rt_render_pool_kernel<1, RT_BLOCK, RT_COOP_POOL, 6>) : reinterpret_cast<const void *>(&rt_render_pool_kernel<0, RT_BLOCK, RT_COOP_POOL, 6>));
     if (sv == 2) return pool_function<2, 1024, RT_WALK_POOL>(trav == 2 ? 1 : trav); // (the flat loop needs the whole image: never asked for here)
     if (kv == 1) return sv == 1 ? pool_function<1, RT_BLOCK, 192>(trav) : pool_function<0, RT_BLOCK, 192>(trav);
     if (kv == 3) return sv == 1 ? pool_function<1, RT_BLOCK, 128>(trav) : pool_function<0, RT_BLOCK, 128>(trav);
@@ -538,6 +619,7 @@ static const void *probe_function_sv(int trav)
     case 2: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, (SV == 2 ? 1 : 2)>); // (flat needs the whole image: never asked for with SV 2)
     case 3: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 3>);
     case 5: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 5>);
+    case 6: return reinterpret_cast<const void *>(&rt_cast_rays_coop_kernel<SV>);
     default: return reinterpret_cast<const void *>(&rt_cast_rays_kernel<SV, 4>);
     }
 }
@@ -558,7 +640,7 @@ struct rsrt_context {
     DevScene scene{};
     bool scene_ready = false;
     uint32_t hybrid_head_f4 = 0, hybrid_pnode_f4 = 0; // mid-size scenes: float4s of nodes + escape links / of the pre-order nodes' top block (0 = none)
-    // ... and the wide walk's LDS image: the first wimg_nodes wide nodes, as many as kHybridRoomF4 holds (0 = no image)
+    // ... and the wide walks' LDS image: a prefix of the wimg_nodes wide nodes, as long as the launch has room for (0 = no image)
     uint32_t wimg_nodes = 0;
     // environments
     std::vector<Env> envs;
@@ -626,9 +708,10 @@ struct rsrt_context {
     // scratch for rsrt_resolve_mean_f16 / rsrt_display_srgb8 (grow-only; no per-frame hipMalloc)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
-    int blocks_per_cu[18][RT_N_VARIANTS] = {}; // [scene view * 6 + traversal][kernel variant]
+    int blocks_per_cu[21][RT_N_VARIANTS] = {}; // [scene view * 7 + traversal][kernel variant]
     int kernel_variant = 4; // index into kVariantPool
-    int max_traversal = 4; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
+    int max_traversal = 6; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
+    uint32_t coop_lds_cap = RT_COOP_NCAP, coop_narrow_at = RT_COOP_NARROW_AT; // RSRT_COOP_LDS_CAP / RSRT_COOP_NARROW_AT (tests: force the node stack's spill / one-item trips)
     bool allow_flat = true;
     bool allow_hybrid = true;
     uint32_t trace_budget = 0; // traversal steps per TRACE invocation before a ray is re-queued (0: 6 for the fixed-order walk, 12 for the tree walks)
@@ -986,7 +1069,6 @@ static bool hybrid_stage(const rsrt_context *ctx, DevScene &sc, int trav, uint32
 {
     sc.lds_wnodes = 0u;
     if (trav >= 4) {
-        // (the image was cut for kHybridRoomF4 at upload; a caller with less room takes what fits)
         sc.lds_wnodes = std::min(ctx->wimg_nodes, room_f4 / 8u);
         if (sc.lds_wnodes == 0) return false;
         sc.lds_float4s = 8u * sc.lds_wnodes;
@@ -1011,6 +1093,7 @@ int select_traversal(const rsrt_context *ctx, const DevScene &sc, uint32_t max_b
     if (ctx->max_traversal >= 2 && ctx->allow_flat && sc.flat_ok && max_bounces <= RT_FLAT_MAX_BOUNCES) return 2;
     // RSRT_FLAG_PRUNE wants the reference's near-child-first order: a close hit found early is what lets later boxes be
     // skipped (the fixed-order walk prunes 4 % of suzanne's steps, the near-first walk 8 %)
+    if (ctx->max_traversal >= 6 && sc.wide_ok && sc.coop_ok && !(flags & RSRT_FLAG_PRUNE)) return 6; // the cooperative walk (rt_coop.h)
     if (ctx->max_traversal >= 4 && sc.wide_ok && !(flags & RSRT_FLAG_PRUNE)) return sc.wide_deep ? 5 : 4; // (5: the same walk with a stack that may overflow into memory)
     if (ctx->max_traversal >= 3 && sc.typed_leaves && !(flags & RSRT_FLAG_PRUNE)) return 3;
     if (ctx->max_traversal >= 1 && sc.typed_leaves) return 1;
@@ -1161,7 +1244,7 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
         return RSRT_ERR_HIP;
     }
     for (int kv = 0; kv < RT_N_VARIANTS; kv++)
-        for (int m = 0; m < 18; m++) (void)hipFuncSetAttribute(variant_function(kv, m / 6, m % 6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int m = 0; m < 21; m++) (void)hipFuncSetAttribute(variant_function(kv, m / 7, m % 7), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (const char *kv = getenv("RSRT_KERNEL")) { // see kVariantPool
         int v = atoi(kv);
         if (v >= 0 && v < RT_N_VARIANTS) ctx->kernel_variant = v;
@@ -1182,8 +1265,10 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     if (const char *pb = getenv("RSRT_PIPE_BLOCKS")) { int v = atoi(pb); if (v >= 1 && v <= 4) ctx->pipe_blocks = v; } // experiment knob
     if (const char *o = getenv("RSRT_BLOCKS_PER_CU")) { int v = atoi(o); if (v > 0) ctx->max_blocks_per_cu = v; } // experiment knob
     if (const char *pr = getenv("RSRT_PROBE_REPEAT")) { int v = atoi(pr); if (v > 1 && v <= 4096) ctx->probe_repeat = (uint32_t)v; }
+    if (const char *cl = getenv("RSRT_COOP_LDS_CAP")) { int v = atoi(cl); if (v >= (int)RT_COOP_MIN_LDS_CAP && v <= (int)RT_COOP_NCAP) ctx->coop_lds_cap = (uint32_t)v; }
+    if (const char *cn = getenv("RSRT_COOP_NARROW_AT")) { int v = atoi(cn); if (v >= 0 && v <= (int)RT_COOP_NARROW_AT) ctx->coop_narrow_at = (uint32_t)v; }
     if (const char *hq = getenv("GPU_MAX_HW_QUEUES")) { int v = atoi(hq); if (v > 0) ctx->hw_queues = v; }
-    for (int m = 0; m < 18; m++) (void)hipFuncSetAttribute(probe_function(m / 6, m % 6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int m = 0; m < 21; m++) (void)hipFuncSetAttribute(probe_function(m / 7, m % 7), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];
     snprintf(buf, sizeof buf, "librsrt 0.1; %s (%s); %d CUs", prop.name, prop.gcnArchName, ctx->cus);
     ctx->description = buf;
@@ -1475,8 +1560,8 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     for (uint32_t e = 0; e < n_pnodes; e++)
         if (plist[e].old != 0xffffffffu) new_id[plist[e].old] = e;
     const size_t pnode_f4 = 2ull * n_pnodes, prank_f4 = (8ull * n_primitives + 3) / 4, wnode_f4 = 8ull * wide.size();
-    // the wide walk's LDS image: the head of the wide-node array (hottest first), as far as the room beside the pools goes
-    const uint32_t wimg_nodes = wide_ok ? std::min<uint32_t>((uint32_t)wide.size(), kHybridRoomF4 / 8u) : 0u;
+    // the wide walks' LDS image: the head of the wide-node array (hottest first), as far as the room beside the launch's pools goes (hybrid_stage)
+    const uint32_t wimg_nodes = wide_ok ? (uint32_t)wide.size() : 0u;
     // ---- build the device image: nodes | prims | escape links | tri normals | materials | fb spheres | fb planes
     const size_t n_f4 = 2ull * n_nodes + 4ull * n_primitives + 3ull * n_triangles + 4ull * n_materials + 4ull * n_spheres + 4ull * n_planes + esc_f4 + flat_f4;
     std::vector<float4> img(n_f4 + rank_f4 + pnode_f4 + prank_f4 + wnode_f4); // what follows the LDS image: flat ranks | pre-order nodes | record ranks | wide nodes
@@ -1543,6 +1628,23 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
         }
         memcpy(p, flat_rank.data(), flat_rank.size() * sizeof(uint32_t));
     }
+    // The cooperative walk (rt_coop.h) folds an extension ray's hits with an atomic minimum and sends a ray that sees two records at the same
+    // closest t through the exact walk once more.  A record that repeats an EARLIER record of its leaf bit for bit gives that record's t to every
+    // ray and can never win (the reference keeps the first of equals; a leaf's records are met in index order whatever the octant): it is
+    // marked in a word no test reads (r2.w) and counts as a miss there, so that doubled geometry does not make every hit a tie.
+    {
+        std::vector<uint32_t> twins;
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            const rsrt_bvh_node &nd = nodes[i];
+            for (uint32_t b = 1; b < nd.primitives_len; b++)
+                for (uint32_t a = 0; a < b; a++)
+                    if (same_test(p_prims + 4 * (nd.primitives_or_second_child_index + a), p_prims + 4 * (nd.primitives_or_second_child_index + b))) {
+                        twins.push_back(nd.primitives_or_second_child_index + b);
+                        break;
+                    }
+        }
+        for (uint32_t r : twins) p_prims[4 * r + 2].w = u2f(1u); // (afterwards: same_test compares these words too)
+    }
     float4 *p_pnodes = img.data() + n_f4 + rank_f4;
     for (uint32_t e = 0; e < n_pnodes; e++) {
         if (plist[e].old == 0xffffffffu) { // jump element: both links equal, box never looked at
@@ -1586,6 +1688,7 @@ rsrt_status rsrt_upload_scene(rsrt_context *ctx, const rsrt_material *materials,
     sc.n_wnodes = (uint32_t)wide.size();
     sc.wide_ok = wide_ok ? 1u : 0u;
     sc.wide_deep = (wide_ok && wide_depth > RT_WSTACK + 1u) ? 1u : 0u;
+    sc.coop_ok = (wide_ok && n_primitives < RT_COOP_MAX_RECORDS && wide.size() < RT_COOP_MAX_NODES) ? 1u : 0u; // (build_wide_tree already bounds the depth at 25 wide levels)
     sc.lds_wnodes = 0u; // (set per launch, hybrid_stage)
     ctx->wimg_nodes = wimg_nodes;
     sc.flat_ok = flat_ok ? 1u : 0u;
@@ -2009,22 +2112,24 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const int trav = select_traversal(ctx, P.scene, max_bounces, flags);
     int sv = P.scene.lds_float4s != 0 ? 1 : 0;
     if (sv == 0 && kv != 0 && ctx->allow_hybrid) { // mid-size scene: what the chosen traversal's box steps touch, in LDS (the first kernel has no hybrid form)
-        if (hybrid_stage(ctx, P.scene, trav, kHybridRoomF4)) sv = 2;
+        if (hybrid_stage(ctx, P.scene, trav, trav == 6 ? kCoopRoomF4 : kHybridRoomF4)) sv = 2;
     }
     // measured on suzanne and the 15 k-triangle grid (profiles/r02_bvh_knobs.txt): with the quorum vote a round is short, and
     // handing the slot back to the scheduler after about one round beats running several rounds with thinning lanes
     P.trace_budget = ctx->trace_budget ? ctx->trace_budget : (trav >= 4 ? 4u : (trav == 3 ? 6u : 12u)); // (wide walk: rounds, not steps)
+    P.coop_lds_cap = ctx->coop_lds_cap;
+    P.coop_narrow_at = ctx->coop_narrow_at;
     // a small job behind a kernel that is still running: the 256-thread form, one workgroup per CU, on one of four lanes (see Lane)
     bool pipelined = false;
-    if (ctx->overlap && kv == 4 && sv == 1 && (uint64_t)P.n_slots * sample_count <= ctx->small_paths && sample_count <= pass_samples)
+    if (ctx->overlap && kv == 4 && sv == 1 && trav != 6 && (uint64_t)P.n_slots * sample_count <= ctx->small_paths && sample_count <= pass_samples)
         for (auto &L : ctx->lanes) pipelined = pipelined || (L.traced_valid && hipEventQuery(L.traced) == hipErrorNotReady);
     const int kv_eff = pipelined ? 2 : kv;
-    const bool big = kv_eff == 4 && sv == 1; // one workgroup per CU shares the scene copy
-    const uint32_t pool = sv == 2 ? RT_WALK_POOL : ((kv_eff == 4 && !big) ? 160u : kVariantPool[kv_eff]);
+    const bool big = kv_eff == 4 && sv == 1 && trav != 6; // one workgroup per CU shares the scene copy
+    const uint32_t pool = trav == 6 ? RT_COOP_POOL : (sv == 2 ? RT_WALK_POOL : ((kv_eff == 4 && !big) ? 160u : kVariantPool[kv_eff]));
     const uint32_t block = (sv == 2 || big) ? 1024u : (uint32_t)RT_BLOCK;
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
-                                : scene_bytes + (size_t)(block / RT_WAVE) * 4u * ((size_t)H_COUNT * pool + pool_list_dwords(trav));
+                                : scene_bytes + (size_t)(block / RT_WAVE) * 4u * pool_wave_lds_dwords(trav, pool);
     if (smem > 160 * 1024) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "kernel needs %zu bytes of LDS (> 160 KiB): bvh too deep for this pool size", smem);
     const void *kfn = variant_function(kv_eff, sv, trav);
     int pipe_blocks = ctx->pipe_blocks; // workgroups per CU of a pipelined small job: four such jobs fill a CU
@@ -2033,7 +2138,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         fprintf(stderr, "librsrt: pipelining single-sample calls over %u streams on %d hardware queues: set GPU_MAX_HW_QUEUES=8 before the first HIP call (INTEGRATION.md)\n",
                 ctx->n_lanes, ctx->hw_queues);
     }
-    int &bpc = pipelined ? pipe_blocks : ctx->blocks_per_cu[sv * 6 + trav][kv];
+    int &bpc = pipelined ? pipe_blocks : ctx->blocks_per_cu[sv * 7 + trav][kv];
     if (bpc == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, (int)block, smem);
@@ -2042,7 +2147,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
         if (ctx->max_blocks_per_cu > 0) bpc = std::min(bpc, ctx->max_blocks_per_cu);
     }
 
-    const size_t need_cold = kv != 0 ? (size_t)ctx->cus * bpc * (block / RT_WAVE) * pool_cold_columns(trav) * pool * sizeof(uint32_t) : 0; // cold path-state arena: one block of columns per wave that can be resident
+    const size_t need_cold = kv != 0 ? (size_t)ctx->cus * bpc * (block / RT_WAVE) * pool_wave_cold_dwords(trav, pool) * sizeof(uint32_t) : 0; // cold path-state arena: one block of columns per wave that can be resident
     // the context's buffers are shared by every call: order this stream after whatever ran last (another stream's
     // render, rsrt_accumulator_clear on the context's own stream, ...) — with lanes, enqueue_pass orders each resolve itself
     if (!ctx->overlap && (st = begin_work(ctx, stream))) return st;
@@ -2165,13 +2270,14 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
     DeviceGuard g(ctx->device);
     if (!ctx->scene_ready) return fail(ctx, RSRT_ERR_NOT_READY, "no scene uploaded");
     if (n == 0) return RSRT_OK;
-    if (!origins || !dirs || !out || mode > 31 || ((mode >> 1) & 7u) > 5u) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: bad arguments");
-    // mode: bit 0 = cast_ray_bvh only; bits 1-3 = traversal (0 threaded, 1 stack, 2 typed leaf loops, 3 flat, 4 fixed-order);
+    if (!origins || !dirs || !out || mode > 31 || ((mode >> 1) & 7u) > 6u) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: bad arguments");
+    // mode: bit 0 = cast_ray_bvh only; bits 1-3 = traversal (0 threaded, 1 stack, 2 typed leaf loops, 3 flat, 4 fixed-order, 5 wide, 6 cooperative wide);
     // bit 4 = scene read from LDS exactly as the production kernel stages it for that traversal (whole image, or for a
     // mid-size scene the nodes + escape links / the pre-order nodes)
     DevScene sc = ctx->scene;
     const uint32_t sel = (mode >> 1) & 7u;
-    const int trav = sel == 0 ? 0 : (sel == 1 ? 4 : (sel == 2 ? 1 : (sel == 3 ? 2 : (sel == 4 ? 3 : 5)))); // (probe numbering: 4 = stack walk, 5 = wide walk)
+    const int trav = sel == 0 ? 0 : (sel == 1 ? 4 : (sel == 2 ? 1 : (sel == 3 ? 2 : (sel == 4 ? 3 : (sel == 5 ? 5 : 6))))); // (probe numbering: 4 = stack walk, 5 = wide walk, 6 = cooperative wide walk)
+    const size_t coop_lds = trav == 6 ? (size_t)(RT_BLOCK / RT_WAVE) * 4u * pool_wave_lds_dwords(6, 64u) : 0u; // the probe's four one-column pools with their stacks
     int sv = 0;
     if (mode & 16u) {
         if (sc.lds_float4s != 0) {
@@ -2180,34 +2286,39 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
             // (what the production kernel stages for that traversal — the probe has no pools beside it; only the stack walk needs a stack)
             const uint32_t all_f4 = 160u * 1024u / (uint32_t)sizeof(float4);
             const uint32_t stack_f4 = trav == 4 ? (uint32_t)(((size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t) + 15u) / 16u) : 0u;
-            if (!hybrid_stage(ctx, sc, trav == 5 ? 4 : (trav == 4 ? 0 : trav), all_f4 > stack_f4 ? all_f4 - stack_f4 : 0u))
+            const uint32_t coop_f4 = (uint32_t)((coop_lds + 15u) / 16u);
+            if (!hybrid_stage(ctx, sc, trav == 5 ? 4 : (trav == 4 ? 0 : trav), all_f4 > stack_f4 + coop_f4 ? all_f4 - stack_f4 - coop_f4 : 0u))
                 return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: this scene is not staged in LDS by the production kernel");
             sv = 2;
         }
     } else {
         sc.lds_float4s = 0;
     }
+    if (trav == 6 && !(sc.wide_ok && sc.coop_ok)) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: the cooperative walk needs what the wide walk needs, fewer than 2^21 records and 2^24 wide nodes");
     if (trav == 5 && !sc.wide_ok) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: the wide walk needs nested boxes, leaves of at most 8 primitives that share no record, and a wide tree of at most 25 levels");
     if ((trav == 1 || trav == 3) && !sc.typed_leaves) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: typed leaf loops need leaves of at most 8 primitives");
     if (trav == 2 && (!sc.flat_ok || sv == 2)) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: the flat traversal needs a scene of at most 64 records with nested boxes");
     { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
     float *d_o = nullptr, *d_d = nullptr;
     rsrt_hit *d_h = nullptr;
+    uint32_t *d_g = nullptr; // (cooperative walk: the waves' overflow blocks)
+    const uint32_t n_blocks = (n + RT_BLOCK - 1) / RT_BLOCK;
     hipError_t e = hipMalloc(&d_o, (size_t)n * 12);
+    if (e == hipSuccess && trav == 6) e = hipMalloc(&d_g, (size_t)n_blocks * (RT_BLOCK / RT_WAVE) * RT_COOP_GCAP * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&d_d, (size_t)n * 12);
     if (e == hipSuccess) e = hipMalloc(&d_h, (size_t)n * sizeof(rsrt_hit));
     if (e == hipSuccess) e = hipMemcpy(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_d, dirs, (size_t)n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        const size_t smem = (size_t)sc.lds_float4s * sizeof(float4) + (trav == 4 ? (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t) : 0u); // (only the stack walk has a stack)
-        if (smem > 160 * 1024) { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: needs %zu bytes of LDS", smem); }
+        const size_t smem = (size_t)sc.lds_float4s * sizeof(float4) + (trav == 4 ? (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t) : 0u) + coop_lds; // (only the stack walk has a stack)
+        if (smem > 160 * 1024) { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); (void)hipFree(d_g); return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: needs %zu bytes of LDS", smem); }
         uint32_t repeat = ctx->probe_repeat;
-        void *kargs[] = {&sc, &n, &d_o, &d_d, &mode, &flags, &repeat, &d_h};
-        e = hipLaunchKernel(probe_function(sv, trav), dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), kargs, smem, ctx->stream);
+        void *kargs[] = {&sc, &n, &d_o, &d_d, &mode, &flags, &repeat, &d_h, &d_g, &ctx->coop_lds_cap, &ctx->coop_narrow_at}; // (the last three: the cooperative walk's probe only)
+        e = hipLaunchKernel(probe_function(sv, trav), dim3(n_blocks), dim3(RT_BLOCK), kargs, smem, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d_h, (size_t)n * sizeof(rsrt_hit), hipMemcpyDeviceToHost);
-    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h);
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); (void)hipFree(d_g);
     if (e != hipSuccess) return fail(ctx, RSRT_ERR_HIP, "cast_rays: %s", hipGetErrorString(e));
     return RSRT_OK;
 }

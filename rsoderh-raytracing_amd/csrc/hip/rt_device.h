@@ -85,6 +85,7 @@ struct DevScene {
     const float4 *wnodes;
     uint32_t n_wnodes, wide_ok;
     uint32_t wide_deep; // the wide tree has more levels than the walk's register stack holds (RT_WSTACK + 1): TRAV 5
+    uint32_t coop_ok;   // ... and the cooperative walk (rt_coop.h, TRAV 6) can name every record and node in its 32-bit work items
     // the wide walk's LDS image (lds_hybrid == 3): the first lds_wnodes wide nodes; everything else is read from global memory
     uint32_t lds_wnodes;
     const float4 *lds_src; // what stage_scene_lds copies (lds_float4s float4s): the image, nodes | escape links, or the pre-order nodes

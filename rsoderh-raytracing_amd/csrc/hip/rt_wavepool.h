@@ -37,6 +37,7 @@
 // two: a third fewer stage switches, and the state crosses the memory system once per bounce.
 #pragma once
 #include "rt_device.h"
+#include "rt_coop.h"
 
 enum HotField { H_OX, H_OY, H_OZ, H_EX, H_EY, H_EZ, H_SX, H_SY, H_SZ, H_T, H_CT, H_COUNT };
 // H_CT: stage tag (3 bits) | flags (4 bits) | cursor of the traversal in progress, or the record of the hit it found (25 bits)
@@ -70,20 +71,28 @@ enum ColdField {
 #define C_COUNT_WIDE_DEEP ((uint32_t)C_COUNT + RT_WSTATE_WORDS) /* TRAV 5: + overflow count and overflow words */
 __host__ __device__ constexpr uint32_t pool_cold_columns(int trav)
 {
-    return trav == 2 ? (uint32_t)C_COUNT_FLAT : (trav == 4 ? C_COUNT_WIDE : (trav == 5 ? C_COUNT_WIDE_DEEP : (uint32_t)C_COUNT));
+    // (6, the cooperative walk: no C_REF — the hit's record waits in the slot's hot result cell — and nothing parked)
+    return trav == 2 ? (uint32_t)C_COUNT_FLAT : (trav == 4 ? C_COUNT_WIDE : (trav == 5 ? C_COUNT_WIDE_DEEP : (trav == 6 ? (uint32_t)C_REF : (uint32_t)C_COUNT)));
 }
 enum PoolTag { TAG_FREE = 0, TAG_TRACE = 1, TAG_MISS = 2, TAG_SHADE = 3, TAG_FINISH = 4, TAG_IDLE = 6 };
 enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_FINISH = 4, ST_COUNT = 5 };
 
-__host__ __device__ constexpr uint32_t pool_list_dwords(int) { return 64u; } // the compaction list: one entry per lane
+// What a wave keeps in LDS: its hot columns (TRAV 6: twelve, rt_coop.h CoopCols — the result cell is two dwords wide), the compaction list
+// (TRAV 6: every waiting ray is traced at once, so the list holds a whole pool — and the walk's leaf stack uses the same words afterwards) and,
+// TRAV 6, the walk's node stack; and in the arena: its cold columns and, TRAV 6, the node stack's overflow block
+__host__ __device__ constexpr uint32_t pool_hot_columns(int trav) { return trav == 6 ? 12u : (uint32_t)H_COUNT; }
+__host__ __device__ constexpr uint32_t pool_list_dwords(int trav) { return trav == 6 ? RT_COOP_LCAP : 64u; }
+__host__ __device__ constexpr uint32_t pool_wave_lds_dwords(int trav, uint32_t pool) { return pool_hot_columns(trav) * pool + pool_list_dwords(trav) + (trav == 6 ? RT_COOP_NCAP : 0u); }
+__host__ __device__ constexpr uint32_t pool_wave_cold_dwords(int trav, uint32_t pool) { return pool_cold_columns(trav) * pool + (trav == 6 ? RT_COOP_GCAP : 0u); }
 template <uint32_t POOL, int TRAV>
 struct PoolLayout {
     static constexpr uint32_t kSlotsPerLane = (POOL + 63u) / 64u;
-    static constexpr uint32_t kHotDwords = (uint32_t)H_COUNT * POOL; // in LDS: every hot column
+    static constexpr uint32_t kHotDwords = pool_hot_columns(TRAV) * POOL; // in LDS: every hot column
     static constexpr uint32_t kListDwords = pool_list_dwords(TRAV);
-    static constexpr uint32_t kWaveLdsDwords = kHotDwords + kListDwords;
+    static constexpr uint32_t kWaveLdsDwords = pool_wave_lds_dwords(TRAV, POOL);
     static constexpr uint32_t kColdColumns = pool_cold_columns(TRAV);
-    static constexpr uint32_t kWaveColdDwords = kColdColumns * POOL;
+    static constexpr uint32_t kWaveColdDwords = pool_wave_cold_dwords(TRAV, POOL);
+    static constexpr uint32_t kCtColumn = pool_hot_columns(TRAV) - 1u; // the tag word is the last hot column
 };
 
 RT_DEV uint32_t stage_of_tag(uint32_t tag) { return tag; } // FREE -> GEN, TRACE, MISS, SHADE, FINISH; IDLE -> none
@@ -114,7 +123,8 @@ RT_DEV void store_sample(float *dst, V3 L) { __builtin_nontemporal_store(rt_f3v{
 // primitives), 2 trace_flat (<= 64 primitive records, nested boxes; rays with a non-finite 1/d fall back to 0),
 // 3 trace_preorder (leaves of <= 8 primitives; fixed order, ties by tabulated visiting rank), 4 trace_wide (4-wide nodes
 // collapsed from the binary tree, a quarter of the dependent fetches; rays with a non-finite 1/d fall back to 3), 5 trace_wide for a
-// tree deeper than the walk's register stack (the bottom of the stack overflows into the slot's arena columns)
+// tree deeper than the walk's register stack (the bottom of the stack overflows into the slot's arena columns), 6 the cooperative wide walk
+// (rt_coop.h: the wave traces all waiting rays together, as (ray, node) and (ray, leaf) items on two LDS stacks; POOL <= 128)
 // SV: where the scene is read from — 0 global memory, 1 the whole image in LDS (256-thread workgroups, several per
 // CU), 2 nodes + escape links in LDS (SceneViewHybrid; BLOCK = 1024: one workgroup per CU shares the copy)
 template <int SV> struct PoolView;
@@ -126,7 +136,8 @@ template <int SV, uint32_t BLOCK, uint32_t POOL, int TRAV>
 __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_kernel(RenderParams P)
 {
     typedef PoolLayout<POOL, TRAV> L;
-    constexpr bool kBounceInCt = pool_cold_columns(TRAV) == (uint32_t)C_COUNT_FLAT; // no C_BOUNCE / C_REF column
+    constexpr bool kCoop = TRAV == 6; // the cooperative wide walk (rt_coop.h): TRACE takes every waiting ray of the pool at once, both rays of a vertex in one call
+    constexpr bool kBounceInCt = TRAV == 2; // no C_BOUNCE / C_REF column
     // Flat traversal: a ray finishes in one TRACE call — or is cut short by the triangle-loop vote with its best t parked where the
     // result would go — so "best t so far" is INFINITY at every fresh start and the H_T cell is
     // only needed for the RESULT of the extension ray — which fits the shadow direction's first cell, dead by then (the
@@ -136,19 +147,19 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     constexpr uint32_t kTCell = kRngHot ? (uint32_t)H_SX : (uint32_t)H_T; // where the extension ray's t waits for SHADE / MISS
     constexpr bool kFlatVote = kRngHot && kBounceInCt; // a TRACE call may return a flat traversal unfinished
     constexpr bool kPackedMiss = TRAV == 2; // MISS reads an escaping ray's pmf from the texels' alpha (rt_device.h)
-    constexpr bool kGenTrace = TRAV >= 2; // GEN traces the camera ray it has built (the near-first tree walks, kept for RSRT_FLAG_PRUNE, would spill)
+    constexpr bool kGenTrace = TRAV >= 2 && !kCoop; // GEN traces the camera ray it has built (the near-first tree walks, kept for RSRT_FLAG_PRUNE, would spill)
     const DevScene &sc = P.scene;
     if (SV != 0) stage_scene_lds(sc);
     const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
-    const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
+    const uint32_t lane0 = threadIdx.x & (RT_WAVE - 1);
     // (readfirstlane: the compiler cannot know that threadIdx.x / 64 is wave-uniform; told so, the wave's LDS and arena bases live in scalar
     // registers and a column access is base + 32-bit lane offset instead of a 64-bit address per lane)
     // (only the walk kernels — the flat kernel, which already holds its cull boxes in scalar registers, runs out of them: +1-1.5 %)
-    constexpr bool kScalarWave = SV == 2;
+    constexpr bool kScalarWave = SV == 2 || TRAV == 6;
     const uint32_t wave = kScalarWave ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / RT_WAVE)) : threadIdx.x / RT_WAVE;
     uint32_t *const lds32 = reinterpret_cast<uint32_t *>(rt_smem + sc.lds_float4s);
     uint32_t *const W = lds32 + wave * L::kWaveLdsDwords; // this wave's hot columns
-    uint32_t *const WCT = W + (uint32_t)H_CT * POOL; // the tag column (the census reads all of it every trip)
+    uint32_t *const WCT = W + L::kCtColumn * POOL; // the tag column (the census reads all of it every trip)
     uint32_t *const list = W + L::kHotDwords;
     uint32_t *const G = P.cold_state + (size_t)(blockIdx.x * (BLOCK / RT_WAVE) + wave) * L::kWaveColdDwords; // cold columns
     const bool prune = (P.flags & RSRT_FLAG_PRUNE) != 0;
@@ -163,12 +174,15 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
 #define TAG_OF(slot) (WCT[(slot)] & 7u)
 #define SET_TAG(slot, tag) WCT[(slot)] = (uint32_t)(tag)              /* no flags, cursor := root (0) */
 #define SET_CT(slot, payload, flags, tag) WCT[(slot)] = ((payload) << CT_SHIFT) | (flags) | (uint32_t)(tag)
+// (TRAV 6: the extension ray's result cell, rt_coop.h CoopCols::BEST)
+#define BEST_REF(slot) W[9u * POOL + 2u * (slot)]
+#define BEST_T(slot) W[9u * POOL + 2u * (slot) + 1u]
 #define COLD(f, slot) G[(f) * POOL + (slot)]
 #define COLDF(f, slot) as_f(G[(f) * POOL + (slot)])
 #define SETC(f, slot, val) G[(f) * POOL + (slot)] = as_u(val)
 
     for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
-        if (lane + 64u * k < POOL) SET_TAG(lane + 64u * k, TAG_FREE);
+        if (lane0 + 64u * k < POOL) SET_TAG(lane0 + 64u * k, TAG_FREE);
     RT_WAVE_HANDOVER();
 
     uint32_t chunk_next = 0, chunk_left = 0, chunk_tile_slot0 = 0, chunk_tx0 = 0, chunk_ty0 = 0, chunk_s0 = 0, chunk_p0 = 0;
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
 
 #ifdef RT_INSTRUMENT
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
-#define DBG_STAMP(i) do { unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) dbg.c[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#define DBG_STAMP(i) do { unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane0 == 0) dbg.c[i] += t_now - t_prev; t_prev = t_now; } while (0)
 #else
 #define DBG_STAMP(i) do { } while (0)
 #endif
@@ -243,6 +257,11 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         ray_end(slot, ct, h, cur, t_in, flat_rem);
     };
     for (;;) {
+        // (TRAV 6: the lane index is made opaque once per trip of the scheduler, so that what is derived from it — a dozen LDS and arena
+        // addresses per stage — is formed where it is used instead of being hoisted out of this loop into registers that then live through
+        // every stage: the kernel stays within 128 registers without scratch memory, tests/test_code_object.py)
+        uint32_t lane = lane0;
+        if (kCoop) asm volatile("" : "+v"(lane));
         DBG_STAMP(21); // previous stage's tail is charged below; this resets the clock for the census
         // ---------------- 1. census of the stage tags (each lane looks at its kSlotsPerLane slots)
         uint32_t tags[L::kSlotsPerLane];
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         const uint32_t slot = on ? list[lane] : 0u;
         const uint32_t dbg_stage = best;
         (void)dbg_stage;
-        if (lane == 0) { DBG_ADD(dbg_stage, 1); DBG_ADD(5 + dbg_stage, n_run); }
+        if (lane == 0) { DBG_ADD(dbg_stage, 1); DBG_ADD(5 + dbg_stage, (kCoop && best == ST_TRACE) ? best_n : n_run); }
         DBG_STAMP(22); // census + compaction
 
         if (best == ST_GEN) {
@@ -310,7 +329,8 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                         start_path(P, px, py, P.sample_begin + srel, ps);
                         SETH(H_OX, slot, ps.o.x); SETH(H_OY, slot, ps.o.y); SETH(H_OZ, slot, ps.o.z);
                         SETH(H_EX, slot, ps.d.x); SETH(H_EY, slot, ps.d.y); SETH(H_EZ, slot, ps.d.z);
-                        if (kRngHot) SETHU(H_T, slot, ps.rng); else SETH(H_T, slot, RT_INFINITY);
+                        if (kRngHot) SETHU(H_T, slot, ps.rng);
+                        else if (!kCoop) SETH(H_T, slot, RT_INFINITY);
                         SETC(C_TX, slot, 1.0f); SETC(C_TY, slot, 1.0f); SETC(C_TZ, slot, 1.0f);
                         SETC(C_LX, slot, 0.0f); SETC(C_LY, slot, 0.0f); SETC(C_LZ, slot, 0.0f);
                         SETC(C_LASTPDF, slot, 1.0f);
@@ -333,6 +353,40 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             if (exhausted) { // nothing more to hand out: park every FREE slot
                 for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
                     if (lane + 64u * k < POOL && TAG_OF(lane + 64u * k) == TAG_FREE) SET_TAG(lane + 64u * k, TAG_IDLE);
+            }
+        } else if (kCoop && best == ST_TRACE) {
+            // ---------------- TRACE, cooperative wide walk: EVERY slot that waits in TRACE (the list holds them all), its shadow ray and its
+            // extension ray at once, as items on the wave's two stacks (rt_coop.h); when the stacks are empty every ray is done
+            if constexpr (kCoop) {
+                CoopStacks cs;
+                cs.ns = list + L::kListDwords; cs.ls = list; cs.gs = G + L::kColdColumns * POOL;
+                cs.ns_n = cs.ls_n = cs.gs_n = 0u;
+                cs.lds_cap = P.coop_lds_cap; cs.narrow_at = P.coop_narrow_at;
+                for (uint32_t i0 = 0; i0 < best_n; i0 += 64u) { // (the list is read to the end before the first leaf item lands in the same words)
+                    const bool valid = i0 + lane < best_n;
+                    const uint32_t s = list[valid ? i0 + lane : 0u];
+                    coop_push_rays<POOL>(W, cs, valid, s, CT_OF(s), (uint32_t)F_EXT, (uint32_t)F_SHADOW);
+                }
+                coop_trace<POOL>(DBG_ARG S, W, cs, anyhit_shadow, lane, n_work);
+                RT_WAVE_HANDOVER();
+                // what each slot is left as (the census's tags are still good: nothing else ran).  First the rays the walk handed to the exact
+                // fixed-order walk: a non-finite 1/d, two records at the same closest t (next to none)
+                uint32_t my_slot[L::kSlotsPerLane];
+                bool mine[L::kSlotsPerLane];
+                for (uint32_t k = 0; k < L::kSlotsPerLane; k++) { my_slot[k] = lane + 64u * k; mine[k] = tags[k] == (uint32_t)TAG_TRACE; }
+                coop_slow_rays<POOL, L::kSlotsPerLane>(DBG_ARG S, sc, W, mine, my_slot, anyhit_shadow, n_work);
+                for (uint32_t k = 0; k < L::kSlotsPerLane; k++) {
+                    if (!mine[k]) continue;
+                    const uint32_t s = my_slot[k], ct = CT_OF(s);
+                    const uint32_t fl = ct & (uint32_t)(F_NEE | F_OCCLUDED);
+                    if (ct & F_SHADOW) n_shadow++;
+                    if (ct & F_EXT) {
+                        n_ext++;
+                        SET_CT(s, 0u, fl, as_f(BEST_T(s)) < RT_INFINITY ? TAG_SHADE : TAG_MISS);
+                    } else {
+                        SET_CT(s, 0u, fl, TAG_FINISH);
+                    }
+                }
             }
         } else if (best == ST_TRACE) {
             // ---------------- TRACE: one ray of the slot from its vertex O — the shadow ray (direction S, any
@@ -378,8 +432,11 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     if (t >= 0.0f && t < h.t) { h.t = t; h.ref = i; h.src = SRC_FB_PLANE; }
                 }
                 if (h.did_hit()) { // SHADE takes it from here (and settles the pending NEE term)
-                    SETH(kTCell, slot, h.t);
-                    if (TRAV == 2) {
+                    if (kCoop) BEST_T(slot) = as_u(h.t); else SETH(kTCell, slot, h.t);
+                    if (kCoop) {
+                        BEST_REF(slot) = h.ref | (h.src << 30);
+                        SET_CT(slot, 0u, ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
+                    } else if (TRAV == 2) {
                         SET_CT(slot, h.ref | (h.src << 6) | (kBounceInCt ? ((ct >> CT_SHIFT) & RT_FLAT_BOUNCE_BITS) : 0u), ct & (F_NEE | F_OCCLUDED), TAG_SHADE);
                     } else {
                         COLD(C_REF, slot) = h.ref | (h.src << 30);
@@ -403,12 +460,12 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
                 const V3 d = v3(HOTF(H_EX, slot), HOTF(H_EY, slot), HOTF(H_EZ, slot));
                 Hit h;
-                h.t = HOTF(kTCell, slot);
+                h.t = kCoop ? as_f(BEST_T(slot)) : HOTF(kTCell, slot);
                 if (TRAV == 2) {
                     const uint32_t hr = (ct >> CT_SHIFT) & 0xffu;
                     h.ref = hr & 63u; h.src = hr >> 6;
                 } else {
-                    const uint32_t hr = COLD(C_REF, slot);
+                    const uint32_t hr = kCoop ? BEST_REF(slot) : COLD(C_REF, slot);
                     h.ref = hr & 0x3fffffffu; h.src = hr >> 30;
                 }
                 DBG_ADD(27, (as_u(hit_record(S, h, 0).w) & 3u) == PRIM_TRIANGLE ? 1 : 0); DBG_ADD(31, (as_u(hit_record(S, h, 0).w) & 3u) == PRIM_SPHERE ? 1 : 0);
@@ -497,7 +554,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     }
                     if (want_shadow) { SETH(H_SX, slot, es.direction.x); SETH(H_SY, slot, es.direction.y); SETH(H_SZ, slot, es.direction.z); }
                     SETH(H_OX, slot, surf.point.x); SETH(H_OY, slot, surf.point.y); SETH(H_OZ, slot, surf.point.z); // both rays start at the hit point
-                    if (!kRngHot) SETH(H_T, slot, RT_INFINITY);
+                    if (!kRngHot && !kCoop) SETH(H_T, slot, RT_INFINITY);
                     SET_CT(slot, kBounceInCt ? (bounce << RT_FLAT_BOUNCE_SHIFT) : 0u,
                            (want_shadow ? (uint32_t)F_SHADOW : 0u) | (finished ? 0u : (uint32_t)F_EXT) | (nee_counts ? (uint32_t)F_NEE : 0u), TAG_TRACE);
                 }
@@ -524,6 +581,8 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
 #undef SET_TAG
 #undef SET_CT
 #undef COLD
+#undef BEST_REF
+#undef BEST_T
 #undef COLDF
 #undef SETC
 
@@ -534,7 +593,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         n_shadow += __shfl_down(n_shadow, off);
         if (TRAV != 2) n_work64 += __shfl_down(n_work64, off);
     }
-    if (lane == 0) {
+    if (lane0 == 0) {
         atomicAdd(&P.stats[0], n_paths);
         atomicAdd(&P.stats[1], n_ext);
         atomicAdd(&P.stats[2], n_shadow);
@@ -544,7 +603,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     for (int i = 0; i < RT_DBG_N; i++) {
         unsigned long long v = dbg.c[i];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0 && v) atomicAdd(&P.stats[4 + i], v);
+        if (lane0 == 0 && v) atomicAdd(&P.stats[4 + i], v);
     }
 #endif
 }

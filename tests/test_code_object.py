@@ -30,7 +30,8 @@ def test_pool_kernels_keep_four_waves_per_simd_without_scratch():
     # LDS or all in global memory; the near-first tree walk RSRT_FLAG_PRUNE selects
     wanted = ["ILi1ELj1024ELj192ELi2EE", "ILi1ELj256ELj160ELi2EE", "ILi2ELj1024ELj192ELi3EE", "ILi0ELj256ELj160ELi3EE", "ILi2ELj1024ELj192ELi1EE", "ILi0ELj256ELj160ELi1EE",
               "ILi2ELj1024ELj192ELi4EE", "ILi0ELj256ELj160ELi4EE",  # the wide walk, top block in LDS / all global
-              "ILi2ELj1024ELj192ELi5EE", "ILi0ELj256ELj160ELi5EE"]  # ... for trees deeper than its register stack
+              "ILi2ELj1024ELj192ELi5EE", "ILi0ELj256ELj160ELi5EE",  # ... for trees deeper than its register stack
+              "ILi2ELj1024ELj128ELi6EE", "ILi0ELj256ELj128ELi6EE", "ILi1ELj256ELj128ELi6EE"]  # the cooperative wide walk: node prefix in LDS / all global / a small scene's whole image (A/B)
     for w in wanted:
         names = [n for n in md if n.startswith("_Z21rt_render_pool_kernel" + w)]
         assert len(names) == 1, (w, names)

@@ -59,9 +59,10 @@ def test_matches_golden_images_bit_exact(name):
 def probe_modes(name):
     """Every way rsrt_cast_rays can run a query (include/rsrt.h): traversal 0 threaded / 1 stack / 2 typed leaf loops /
     3 flat (what house, default and cube run in production; suzanne's 968 triangles do not qualify) / 4 fixed-order walk
-    / 5 wide walk (4-wide nodes; what suzanne and anything bigger run), x scene read from global memory or from LDS as the production kernel stages
+    / 5 wide walk (4-wide nodes, one ray a lane) / 6 cooperative wide walk (the same nodes, a wave's rays as work items on two LDS stacks: what
+    suzanne and anything bigger run), x scene read from global memory or from LDS as the production kernel stages
     it for that traversal (bit 4), x cast_ray / cast_ray_bvh (bit 0)."""
-    sels = [0, 1, 2, 4, 5] + ([3] if name != "suzanne" else [])  # (5: the wide walk — every builder-made tree qualifies)
+    sels = [0, 1, 2, 4, 5, 6] + ([3] if name != "suzanne" else [])  # (5, 6: the wide walks — every builder-made tree qualifies)
     return [(sel << 1) | lds | bvh_only for sel in sels for lds in (0, 16) for bvh_only in (0, 1)]
 
 
@@ -86,7 +87,7 @@ def test_probe_refuses_a_traversal_the_scene_does_not_qualify_for():
     with pytest.raises(R.RsrtError, match="bad arguments"):
         st.cast_rays(o, d, 32, 0)
     with pytest.raises(R.RsrtError, match="bad arguments"):
-        st.cast_rays(o, d, 6 << 1, 0)
+        st.cast_rays(o, d, 7 << 1, 0)
     st.close()
     # a tree whose boxes do not nest (a leaf box pushed out of its parent's) keeps the fixed-order walk: the wide walk is refused
     sc = R.Scene.load_toml(util.scene_path("default"))
@@ -98,6 +99,8 @@ def test_probe_refuses_a_traversal_the_scene_does_not_qualify_for():
     st = R.State.new(bad, golden_env(), 16, 16)
     with pytest.raises(R.RsrtError, match="wide walk"):
         st.cast_rays(o, d, 5 << 1, 0)
+    with pytest.raises(R.RsrtError, match="cooperative walk"):
+        st.cast_rays(o, d, 6 << 1, 0)
     st.cast_rays(o, d, 4 << 1, 0)
     st.close()
 
@@ -114,12 +117,12 @@ def test_matches_oracle_live(name, w, h, spp, mb, big_env):
     assert (st["paths"], st["ext_rays"], st["shadow_rays"]) == (ost["paths"], ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("variant,traversal", [("0", "4"), ("1", "4"), ("2", "4"), ("3", "4"), ("4", "4"), ("2", "4-noflat"), ("4", "4-noflat"), ("2", "3"), ("4", "3"), ("2", "3-noflat"), ("4", "3-noflat"), ("2", "1"), ("4", "1"), ("2", "0")])
+@pytest.mark.parametrize("variant,traversal", [("4", "6"), ("2", "6"), ("4", "6-noflat"), ("1", "6-noflat"), ("0", "4"), ("1", "4"), ("2", "4"), ("3", "4"), ("4", "4"), ("2", "4-noflat"), ("4", "4-noflat"), ("2", "3"), ("4", "3"), ("2", "3-noflat"), ("4", "3-noflat"), ("2", "1"), ("4", "1"), ("2", "0")])
 def test_every_kernel_variant_is_bit_exact(variant, traversal, big_env, monkeypatch):
     """RSRT_KERNEL: 0 = lockstep megakernel, 1/2/3 = stage-scheduled wave-pool kernel (192/160/128 slots per wave), 4 (the
     default) = one 1024-thread workgroup and one scene copy per CU for scenes that fit LDS, 192 slots per wave;
-    RSRT_TRAVERSAL caps the traversal: 4 = product (flat loop for small scenes, wide walk otherwise; with RSRT_FLAT=0 the
-    wide walk for small scenes too), 3 = the fixed-order walk instead of the wide one, 1 tree walk with per-type leaf loops, 0 generic tree walk.
+    RSRT_TRAVERSAL caps the traversal: 6 = product (flat loop for small scenes, cooperative wide walk otherwise; with RSRT_FLAT=0 that
+    walk for small scenes too), 4 = the one-ray-a-lane wide walk instead, 3 = the fixed-order walk instead of the wide one, 1 tree walk with per-type leaf loops, 0 generic tree walk.
     Scheduling differs, the per-path arithmetic does not: all must give the oracle's bits."""
     monkeypatch.setenv("RSRT_KERNEL", variant)
     monkeypatch.setenv("RSRT_TRAVERSAL", traversal[0])
@@ -510,14 +513,15 @@ def test_bvh_whose_boxes_do_not_nest_keeps_the_tree_walk(big_env):
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("traversal", ["4", "4-noflat", "3", "3-q100", "3-noflat", "1", "0"])
+@pytest.mark.parametrize("traversal", ["6-noflat", "4", "4-noflat", "3", "3-q100", "3-noflat", "1", "0"])
 def test_twin_records_in_different_leaves_tie_by_visiting_order(traversal, big_env, monkeypatch):
     """A sphere exists twice, with two materials, and its copies sit in DIFFERENT leaves (the builder would never do that — equal
     centroids share a leaf — so the BVH is edited by hand: the copy is appended to the last leaf, whose box and whose
     ancestors' boxes grow to hold it).  Every hit on it is a tie of equal t between two leaves; the reference keeps the one it
     visits first, which depends on the ray's sign octant, and the winner's material shows.  The flat traversal ("3": the octant's
     tabulated rank; "3-q100": with its triangle loop cut as often as can be), the fixed-order walk and the tree walks must agree
-    with the oracle; the twin may NOT be dropped the way a twin inside one leaf is."""
+    with the oracle; the twin may NOT be dropped the way a twin inside one leaf is.  The cooperative walk ("6-noflat") folds hits with an
+    atomic minimum over (t, record): it must notice the equal t and send such a ray through the exact walk again."""
     from rsoderh_raytracing_amd import types as T
     monkeypatch.setenv("RSRT_TRAVERSAL", traversal[0])
     if traversal.endswith("noflat"):
@@ -610,7 +614,7 @@ def test_flat_triangle_vote_does_not_change_the_image(quorum, big_env, monkeypat
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("traversal", ["4", "4-noflat", "3", "3-q100", "3-noflat", "1", "0"])
+@pytest.mark.parametrize("traversal", ["6-noflat", "4", "4-noflat", "3", "3-q100", "3-noflat", "1", "0"])
 def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_env, monkeypatch):
     """Every primitive exists three times, at the same place, with three different materials, so every hit is a
     tie of equal t between records that usually sit in different leaves.  The reference keeps the first one it
@@ -662,7 +666,7 @@ def test_coincident_primitives_resolve_ties_like_the_reference(traversal, big_en
     assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
 
 
-@pytest.mark.parametrize("hybrid,traversal", [("1", "4"), ("0", "4"), ("1", "3"), ("0", "3"), ("1", "1"), ("0", "1")])
+@pytest.mark.parametrize("hybrid,traversal", [("1", "6"), ("0", "6"), ("1", "4"), ("0", "4"), ("1", "3"), ("0", "3"), ("1", "1"), ("0", "1")])
 def test_mid_size_scene_with_nodes_in_lds_or_in_global_memory(hybrid, traversal, big_env, monkeypatch):
     """suzanne (968 triangles): too big for the LDS image; by default what its box steps touch — the pre-order nodes of
     the fixed-order walk, or the nodes and escape links of the tree walk (RSRT_TRAVERSAL=1) — is staged in LDS for one
@@ -695,21 +699,26 @@ def test_big_scene_all_global_is_bit_exact(big_env):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     hits = oracle.cast_rays(util.oracle_scene(sc), o, d, 0, 0)
     s2 = R.State.new(sc, util.small_env(), 16, 16)
-    for mode in (0 << 1, 2 << 1, 4 << 1, 5 << 1, (5 << 1) | 16):
+    for mode in (0 << 1, 2 << 1, 4 << 1, 5 << 1, (5 << 1) | 16, 6 << 1, (6 << 1) | 16):
         got = s2.cast_rays(o, d, mode, 0)
         assert np.array_equal(np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9), hits.view(np.uint32).reshape(-1, 9)), mode
     s2.close()
 
 
-@pytest.mark.parametrize("levels,budget,hybrid,kernel", [(42, "", "1", "4"), (60, "", "1", "4"), (60, "1", "1", "4"), (60, "1", "0", "4"), (60, "1", "0", "1"), (60, "", "0", "3")])
+@pytest.mark.parametrize("levels,budget,hybrid,kernel", [(42, "", "1", "4"), (60, "", "1", "4"), (60, "1", "1", "4"), (60, "1", "0", "4"), (60, "1", "0", "1"), (60, "", "0", "3"),
+                                                         (42, "coop", "1", "4"), (60, "coop", "1", "4"), (60, "coop", "0", "4")])
 def test_wide_walk_stack_overflow_on_a_chain_tree(levels, budget, hybrid, kernel, big_env, monkeypatch):
     """tests/util.py deck_scene: a hand-built chain tree whose wide form has levels / 3 levels, on which a ray along the deck holds up to
     13 (42 levels) or 19 (60) stack words — more than the walk has registers (test_wide_tree.py shows that on the CPU).  The image, seen
     along the deck, and a batch of probe rays must be the oracle's bit for bit: with the default budget, and with one round per TRACE
     call, so that rays are parked and resumed while words sit in the overflow area.  42 levels: the scene's whole image fits LDS (scene
     view 1); 60: nodes staged in LDS (view 2) or everything in global memory (RSRT_HYBRID=0, view 0) with 160 / 192 / 128-slot pools."""
-    if budget:
-        monkeypatch.setenv("RSRT_TRACE_BUDGET", budget)
+    if budget == "coop":  # the same trees through the cooperative walk, which has no per-ray stack to overflow (its work stacks are the wave's)
+        monkeypatch.setenv("RSRT_TRAVERSAL", "6")
+    else:
+        monkeypatch.setenv("RSRT_TRAVERSAL", "5")
+        if budget:
+            monkeypatch.setenv("RSRT_TRACE_BUDGET", budget)
     monkeypatch.setenv("RSRT_HYBRID", hybrid)
     monkeypatch.setenv("RSRT_KERNEL", kernel)
     monkeypatch.setenv("RSRT_FLAT", "0")
@@ -726,13 +735,13 @@ def test_wide_walk_stack_overflow_on_a_chain_tree(levels, budget, hybrid, kernel
     hits = oracle.cast_rays(util.oracle_scene(sc), o, d, 0, 0)
     assert hits["did_hit"].sum() > 1024
     s2 = R.State.new(sc, util.small_env(), 16, 16)
-    for mode in (4 << 1, 5 << 1):
+    for mode in (4 << 1, 5 << 1, 6 << 1):
         got = s2.cast_rays(o, d, mode, 0)
         assert np.array_equal(np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9), hits.view(np.uint32).reshape(-1, 9)), mode
     s2.close()
 
 
-@pytest.mark.parametrize("budget", ["", "1"])
+@pytest.mark.parametrize("budget", ["", "1", "coop"])
 def test_scene_with_a_deep_tree_takes_the_wide_walk(budget, big_env, monkeypatch):
     """suzanne on an 8 x 8 grid (61,952 triangles, binary depth 19): the wide tree has eleven levels, more than the walk's eight stack
     registers can always serve, so the scene runs the kernel variant whose stack may overflow into memory (TRAV 5) — on THIS scene no
@@ -742,8 +751,12 @@ def test_scene_with_a_deep_tree_takes_the_wide_walk(budget, big_env, monkeypatch
     import sys
     sys.path.insert(0, util.ROOT + "/tools")
     import make_big_scene
-    if budget:
-        monkeypatch.setenv("RSRT_TRACE_BUDGET", budget)
+    if budget == "coop":  # (the product's choice for this scene since round 4: the cooperative walk, which needs no stack variant)
+        monkeypatch.setenv("RSRT_TRAVERSAL", "6")
+    else:
+        monkeypatch.setenv("RSRT_TRAVERSAL", "5")
+        if budget:
+            monkeypatch.setenv("RSRT_TRACE_BUDGET", budget)
     sc = R.Scene.load_toml(make_big_scene.make(8))
     assert len(sc.triangles) == 61952 and sc.bvh_depth >= 18
     ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 160, 90, 0, 2, 10, fast=True)
@@ -755,14 +768,44 @@ def test_scene_with_a_deep_tree_takes_the_wide_walk(budget, big_env, monkeypatch
     img3, st3 = gpu_render(sc, big_env, 160, 90, 0, 2, 10)
     assert np.array_equal(util.bits(img3), util.bits(ref))
     assert wide_steps < 0.5 * st3["traversal_steps"] / (st3["ext_rays"] + st3["shadow_rays"]), wide_steps
-    if not budget:
+    if budget in ("", "coop"):
         rng = np.random.default_rng(6)
         o = rng.uniform(-12, 12, (4096, 3)).astype(np.float32) + np.float32([0, 2, -8])
         d = rng.normal(size=(4096, 3)).astype(np.float32)
         d /= np.linalg.norm(d, axis=1, keepdims=True)
         hits = oracle.cast_rays(util.oracle_scene(sc), o, d, 0, 0)
         s2 = R.State.new(sc, util.small_env(), 16, 16)
-        for mode in (4 << 1, 5 << 1, (5 << 1) | 16):
+        for mode in (4 << 1, 5 << 1, (5 << 1) | 16, 6 << 1, (6 << 1) | 16):
+            got = s2.cast_rays(o, d, mode, 0)
+            assert np.array_equal(np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9), hits.view(np.uint32).reshape(-1, 9)), mode
+        s2.close()
+
+
+@pytest.mark.parametrize("lds_cap,narrow_at", [("320", ""), ("320", "40"), ("", "0")])
+def test_cooperative_walk_spills_and_narrow_trips_do_not_change_the_image(lds_cap, narrow_at, big_env, monkeypatch):
+    """The cooperative walk's node stack (rt_coop.h): with its LDS part capped at the minimum (RSRT_COOP_LDS_CAP=320) a batch of up to 256 rays
+    spills the stack's bottom to the wave's arena block and takes it back; with RSRT_COOP_NARROW_AT small a wave pops ONE item a trip whenever
+    more than that many items are outstanding (0: always — a plain depth-first walk of the whole batch).  Which items travel together must be
+    invisible: suzanne and the 15 k-triangle grid, reduced frames, bit for bit against the oracle, and the probe."""
+    import sys
+    sys.path.insert(0, util.ROOT + "/tools")
+    import make_big_scene
+    if lds_cap:
+        monkeypatch.setenv("RSRT_COOP_LDS_CAP", lds_cap)
+    if narrow_at:
+        monkeypatch.setenv("RSRT_COOP_NARROW_AT", narrow_at)
+    for sc, w, h, spp in [(R.Scene.load_toml(util.scene_path("suzanne")), 96, 64, 3), (R.Scene.load_toml(make_big_scene.make(4)), 120, 68, 2)]:
+        ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), w, h, 0, spp, 10, fast=True)
+        img, st = gpu_render(sc, big_env, w, h, 0, spp, 10)
+        assert np.array_equal(util.bits(img), util.bits(ref))
+        assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+        rng = np.random.default_rng(8)
+        o = rng.uniform(-6, 6, (2048, 3)).astype(np.float32) + np.float32([0, 2, 2])
+        d = rng.normal(size=(2048, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        hits = oracle.cast_rays(util.oracle_scene(sc), o, d, 0, 0)
+        s2 = R.State.new(sc, util.small_env(), 16, 16)
+        for mode in (6 << 1, (6 << 1) | 16):
             got = s2.cast_rays(o, d, mode, 0)
             assert np.array_equal(np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9), hits.view(np.uint32).reshape(-1, 9)), mode
         s2.close()
