@@ -8,10 +8,13 @@
 // of work is not a ray but an ITEM:
 //     node item  (ray, wide node)          -> four exact box tests; a hit interior child is a new node item, a hit leaf a leaf item
 //     leaf item  (ray, first record, n)    -> n primitive tests (n <= 8: one leaf of the reference's tree)
-// and the wave keeps two LIFO stacks of them in LDS.  A trip pops up to 64 items — one per lane, any ray — and pushes what they turn up
-// with wave64 ballots + prefix popcounts (the compaction north_star names, at item granularity).  A lane is idle only when a stack holds
-// fewer than 64 items, i.e. at the very end of a batch; there are no rounds, no votes, no per-ray stack, nothing to park: every ray of the
-// batch is finished when the stacks are empty.  The rays live where TRACE's rays always lived, in the pool's hot LDS columns, addressed by
+// and the wave keeps two lists of them in LDS: a QUEUE of node items (a ring: oldest first) and a stack of leaf items.  A trip pops up to 64
+// items — one per lane, any ray — and pushes what they turn up with wave64 ballots + prefix popcounts (the compaction north_star names, at item
+// granularity).  A lane is idle only when a list holds fewer than 64 items, i.e. at the very end of a batch; there are no rounds, no votes, no
+// per-ray stack, nothing to park: every ray of the batch is finished when both lists are empty.  Node items go oldest first because that keeps
+// the end of a batch short: the shallow items, whose subtrees take the most trips, are worked off while there is plenty beside them, and what is
+// left at the end are the deep ones, one trip from their leaves (newest first, the last old item's whole subtree was walked alone: 72-78 % of
+// the lanes busy in the node trips instead of 90 %, tools/coop_sim.py and profiles/r04_coop_walk.txt).  The rays live where TRACE's rays always lived, in the pool's hot LDS columns, addressed by
 // slot; a lane reads the ray of its item from there (six LDS dwords) instead of keeping one ray in registers.
 //
 // Results.  Extension ray: one 64-bit LDS cell per slot, t's bits << 32 | record, folded with ds_min_u64 — accepted t are positive floats,
@@ -22,17 +25,20 @@
 // Shadow ray: only did_hit is read (shader.wgsl:1249), so a hit ORs F_OCCLUDED into the slot's tag word and the ray's other items are
 // dropped as they surface.
 //
-// The node stack can outgrow LDS (a batch of 256 rays in a deep tree): its BOTTOM is spilled to the wave's arena block in units of 64 items
-// and comes back when the LDS part runs low; should even that fill up, the wave pops ONE item a trip — a plain depth-first walk, which adds
-// at most three items a level — until it has room again (coop_narrow_at; tests/test_gpu_parity.py forces both).
+// The node queue can outgrow LDS (a batch of 256 rays in a deep tree).  Three steps keep it bounded: beyond coop_lifo_at outstanding items the
+// wave pops the NEWEST 64 instead of the oldest (depth first: the frontier stops growing with the breadth of the tree); what still does not fit
+// the ring is spilled to the wave's arena block, newest 64 items at a time, and comes back when the ring runs low; and should even that block
+// fill up (coop_narrow_at), the wave pops ONE newest item a trip — a plain depth-first walk, which adds at most three items a level — until it
+// has room again (tests/test_gpu_parity.py forces all three).
 #pragma once
 #include "rt_device.h"
 
-#define RT_COOP_NCAP 384u   // node-stack entries in LDS
+#define RT_COOP_NCAP 384u   // node-queue entries in LDS (a ring)
 #define RT_COOP_LCAP 320u   // leaf-stack entries in LDS: 63 may wait, one node trip adds at most 4 x 64; the pool kernel's compaction list lives here too
 #define RT_COOP_GCAP 4096u  // node items a wave may spill to its arena block
 #define RT_COOP_MIN_LDS_CAP 320u // (run-time cap of the LDS part, tests: 63 + 256 must fit after the spills)
 #define RT_COOP_NARROW_AT 3072u  // outstanding node items beyond which a wave pops one item a trip: GCAP - 3072 - 256 - 64 >= 3 x (wide levels <= 25)
+#define RT_COOP_LIFO_AT 512u     // ... beyond which it pops the newest 64 instead of the oldest (0: always — the first version, A/B)
 #define RT_COOP_MAX_RECORDS (1u << 21) // a leaf item names its first record in 21 bits
 #define RT_COOP_MAX_NODES (1u << 24)   // a node item names its node in 24 bits
 // item = slot << 25 | kind << 24 | payload (kind 1: the slot's shadow ray); node item payload = wide node, leaf item payload = first record << 3 | (records - 1)
@@ -68,11 +74,17 @@ RT_DEV bool coop_ray_ok(V3 o, V3 d)
     return short_ok & (finite == 0.0f);
 }
 
-// The wave's two stacks.  Every member is wave-uniform (scalar registers): counts come from ballots.
+// The wave's two lists.  Every member is wave-uniform (scalar registers): counts come from ballots.
 struct CoopStacks {
-    uint32_t *ns, *ls, *gs; // node stack (LDS), leaf stack (LDS), the node stack's spilled bottom (global, this wave's arena block)
-    uint32_t ns_n, ls_n, gs_n;
-    uint32_t lds_cap, narrow_at;
+    uint32_t *ns, *ls, *gs; // node queue (LDS ring of RT_COOP_NCAP entries), leaf stack (LDS), the node queue's overflow (global, this wave's arena block)
+    uint32_t ns_h, ns_n;    // the ring's head (oldest item) and fill
+    uint32_t ls_n, gs_n;
+    uint32_t lds_cap, lifo_at, narrow_at;
+    RT_DEV uint32_t ring(uint32_t i) const // the ring's i-th entry, counted from the head (i < 2 * RT_COOP_NCAP - head)
+    {
+        const uint32_t k = ns_h + i;
+        return k >= RT_COOP_NCAP ? k - RT_COOP_NCAP : k;
+    }
 };
 
 // Root items for up to 64 slots (one per lane; `valid` lanes name a slot whose tag word `ct` says which rays to trace: F_EXT 16, F_SHADOW 8).
@@ -94,20 +106,19 @@ RT_DEV void coop_push_rays(uint32_t *W, CoopStacks &st, bool valid, uint32_t slo
         if (want_e) { W[C::BEST + 2u * slot] = 0u; W[C::BEST + 2u * slot + 1u] = as_u(RT_INFINITY); }
     }
     const unsigned long long be = __ballot(push_e), bs = __ballot(push_s);
-    if (push_e) st.ns[st.ns_n + coop_lanes_below(be)] = slot << 25;
+    if (push_e) st.ns[st.ring(st.ns_n + coop_lanes_below(be))] = slot << 25;
     st.ns_n += (uint32_t)__popcll(be);
-    if (push_s) st.ns[st.ns_n + coop_lanes_below(bs)] = (slot << 25) | RT_COOP_KIND;
+    if (push_s) st.ns[st.ring(st.ns_n + coop_lanes_below(bs))] = (slot << 25) | RT_COOP_KIND;
     st.ns_n += (uint32_t)__popcll(bs);
 }
 
-// Room for `n_new` (<= 256) more node items in LDS: the stack's bottom goes to the arena, 64 items at a time, the rest moves down.
+// Room for `n_new` (<= 256) more node items in the ring: the newest go to the arena, 64 items at a time.
 RT_DEV void coop_make_room(CoopStacks &st, uint32_t n_new, uint32_t lane)
 {
     while (st.ns_n + n_new > st.lds_cap && st.ns_n >= 64u && st.gs_n + 64u <= RT_COOP_GCAP) { // (wave-uniform)
-        st.gs[st.gs_n + lane] = st.ns[lane];
-        st.gs_n += 64u;
-        for (uint32_t i = lane; i + 64u < st.ns_n; i += 64u) st.ns[i] = st.ns[i + 64u]; // (upwards: a trip reads above what it writes)
         st.ns_n -= 64u;
+        st.gs[st.gs_n + lane] = st.ns[st.ring(st.ns_n + lane)];
+        st.gs_n += 64u;
     }
 }
 
@@ -125,6 +136,12 @@ template <uint32_t POOL, class View>
 RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool anyhit_shadow, uint32_t lane, uint32_t &work)
 {
     typedef CoopCols<POOL> C;
+#ifdef RT_INSTRUMENT // (diagnostic build: wave time of the node trips / of the leaf trips, counters 25 / 26)
+    unsigned long long t_trip = __builtin_amdgcn_s_memtime();
+#define COOP_STAMP(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0u) dbg.c[i] += t_now - t_trip; t_trip = t_now; } while (0)
+#else
+#define COOP_STAMP(i) do { } while (0)
+#endif
     for (;;) {
         // the hand-over between trips: items, result cells and flags are written by one lane and read by another
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -132,7 +149,7 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (st.ls_n >= 64u || (st.ns_n == 0u && st.gs_n == 0u && st.ls_n != 0u)) {
             // ---------------- leaf trip: one leaf item a lane, its records two at a time
-            DBG_WAVE_TICK(12);
+            DBG_WAVE_TICK(14); // (diagnostic build: 14 / 28 leaf trips and their items, 12 / 13 record-loop trips and tests, 10 / 11 node trips and items)
             const uint32_t n_take = min(st.ls_n, 64u);
             const bool act0 = lane < n_take;
             const uint32_t item = st.ls[act0 ? st.ls_n - 1u - lane : 0u];
@@ -149,8 +166,10 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
             // a shadow ray that is already occluded needs nothing more (any hit: only did_hit is read)
             uint32_t left = (act0 & !(shadow & anyhit_shadow & ((ct & CF_OCCLUDED) != 0u))) ? (item & 7u) + 1u : 0u;
             work += left;
+            DBG_ADD(28, left != 0u ? 1 : 0); DBG_ADD(29, act0 ? 1 : 0);
             while (left != 0u) {
-                DBG_ADD(13, 1);
+                DBG_WAVE_TICK(12);
+                DBG_ADD(13, left >= 2u ? 2 : 1);
                 const bool two = left >= 2u;
                 const uint32_t rec_a = rec, rec_b = two ? rec + 1u : rec;
                 float4 ra[3], rb[3];
@@ -186,12 +205,13 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
                 rec += 2u;
                 left = left > 2u ? left - 2u : 0u;
             }
+            COOP_STAMP(26);
             continue;
         }
         // ---------------- node trip
-        if (st.ns_n < 64u && st.gs_n != 0u) { // the spilled bottom comes back, a block at a time (order is free)
+        if (st.ns_n < 64u && st.gs_n != 0u) { // what was spilled comes back, a block at a time (order is free)
             st.gs_n -= 64u;
-            st.ns[st.ns_n + lane] = st.gs[st.gs_n + lane];
+            st.ns[st.ring(st.ns_n + lane)] = st.gs[st.gs_n + lane];
             st.ns_n += 64u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -199,9 +219,16 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
         }
         if (st.ns_n == 0u) break; // both stacks empty, nothing spilled: every ray of the batch is done
         DBG_WAVE_TICK(10);
-        const uint32_t n_take = (st.ns_n + st.gs_n > st.narrow_at) ? 1u : min(st.ns_n, 64u);
+        const uint32_t n_out = st.ns_n + st.gs_n;
+        const uint32_t n_take = n_out > st.narrow_at ? 1u : min(st.ns_n, 64u);
         const bool act0 = lane < n_take;
-        const uint32_t item = st.ns[act0 ? st.ns_n - 1u - lane : 0u];
+        uint32_t item;
+        if (n_out > st.lifo_at) { // (wave-uniform) the newest: depth first
+            item = st.ns[st.ring(act0 ? st.ns_n - 1u - lane : 0u)];
+        } else { // the oldest
+            item = st.ns[st.ring(act0 ? lane : 0u)];
+            st.ns_h = st.ring(n_take);
+        }
         st.ns_n -= n_take;
         const uint32_t slot = item >> 25;
         const bool shadow = (item & RT_COOP_KIND) != 0u;
@@ -227,7 +254,7 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
             hm |= !(t_0 > t_1) ? (1u << k) : 0u;
         }
         hm = act ? hm : 0u;
-        DBG_ADD(11, act ? 1 : 0);
+        DBG_ADD(11, act ? 1 : 0); DBG_ADD(30, act0 ? 1 : 0);
         const uint32_t wa = as_u(n[0].w), head = item & RT_COOP_HEAD;
         const uint32_t im = hm & (wa >> 26), child0 = wa & 0x3ffffffu, rec_base = as_u(n[1].w);
         work += act ? 1u : 0u;
@@ -242,7 +269,7 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
         if (st.ns_n + n_new > st.lds_cap) coop_make_room(st, n_new, lane);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (((im >> k) & 1u) != 0u) st.ns[st.ns_n + coop_lanes_below(bi[k])] = head | (child0 + (uint32_t)k);
+            if (((im >> k) & 1u) != 0u) st.ns[st.ring(st.ns_n + coop_lanes_below(bi[k]))] = head | (child0 + (uint32_t)k);
             st.ns_n += (uint32_t)__popcll(bi[k]);
         }
         // ---- ... and the hit leaves: one item each, first record and count (a leaf's records are a run of its node's)
@@ -253,7 +280,9 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
             if (m != 0u) st.ls[st.ls_n + coop_lanes_below(bl)] = head | ((rec_base + (uint32_t)__builtin_ctz(m)) << 3) | ((uint32_t)__popc(m) - 1u);
             st.ls_n += (uint32_t)__popcll(bl);
         }
+        COOP_STAMP(25);
     }
+#undef COOP_STAMP
 }
 
 // The rays the walk could not take or could not decide (CF_SLOW_E / CF_SLOW_S / CF_TIE in the slot's tag word) by the exact fixed-order walk,

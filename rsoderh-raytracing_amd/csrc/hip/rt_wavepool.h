@@ -276,6 +276,16 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         uint32_t best = ST_COUNT, best_n = 0;
         for (uint32_t s = 0; s < ST_COUNT; s++)
             if (count[s] >= best_n && count[s] > 0) { best = s; best_n = count[s]; }
+        if (kCoop && P.coop_defer != 0u && count[ST_TRACE] > 0u) {
+            // The cooperative walk takes EVERY waiting ray at once and keeps its lanes busy whatever their number — but each call ends with a
+            // tail of thin trips, so the more rays a call, the better; the other stages run one slot a lane and want full batches.  So TRACE
+            // waits while some other stage has at least P.coop_defer slots to run (0: plain "fullest stage first", A/B)
+            uint32_t ob = ST_COUNT, on_ = 0u;
+            for (uint32_t s = 0; s < ST_COUNT; s++)
+                if (s != ST_TRACE && count[s] >= on_ && count[s] > 0u) { ob = s; on_ = count[s]; }
+            if (ob == ST_COUNT || on_ < P.coop_defer) { best = ST_TRACE; best_n = count[ST_TRACE]; }
+            else { best = ob; best_n = on_; }
+        }
         if (best == ST_COUNT) break; // nothing left anywhere
         // ---------------- 3. compaction: dense list of the chosen stage's slots
         uint32_t base = 0;
@@ -360,8 +370,8 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             if constexpr (kCoop) {
                 CoopStacks cs;
                 cs.ns = list + L::kListDwords; cs.ls = list; cs.gs = G + L::kColdColumns * POOL;
-                cs.ns_n = cs.ls_n = cs.gs_n = 0u;
-                cs.lds_cap = P.coop_lds_cap; cs.narrow_at = P.coop_narrow_at;
+                cs.ns_h = cs.ns_n = cs.ls_n = cs.gs_n = 0u;
+                cs.lds_cap = P.coop_lds_cap; cs.lifo_at = P.coop_lifo_at; cs.narrow_at = P.coop_narrow_at;
                 for (uint32_t i0 = 0; i0 < best_n; i0 += 64u) { // (the list is read to the end before the first leaf item lands in the same words)
                     const bool valid = i0 + lane < best_n;
                     const uint32_t s = list[valid ? i0 + lane : 0u];

@@ -781,17 +781,21 @@ def test_scene_with_a_deep_tree_takes_the_wide_walk(budget, big_env, monkeypatch
         s2.close()
 
 
-@pytest.mark.parametrize("lds_cap,narrow_at", [("320", ""), ("320", "40"), ("", "0")])
-def test_cooperative_walk_spills_and_narrow_trips_do_not_change_the_image(lds_cap, narrow_at, big_env, monkeypatch):
-    """The cooperative walk's node stack (rt_coop.h): with its LDS part capped at the minimum (RSRT_COOP_LDS_CAP=320) a batch of up to 256 rays
-    spills the stack's bottom to the wave's arena block and takes it back; with RSRT_COOP_NARROW_AT small a wave pops ONE item a trip whenever
-    more than that many items are outstanding (0: always — a plain depth-first walk of the whole batch).  Which items travel together must be
-    invisible: suzanne and the 15 k-triangle grid, reduced frames, bit for bit against the oracle, and the probe."""
+@pytest.mark.parametrize("lds_cap,lifo_at,narrow_at", [("320", "", ""), ("320", "3072", ""), ("320", "64", "40"), ("", "", "0"), ("", "0", "")])
+def test_cooperative_walk_spills_and_narrow_trips_do_not_change_the_image(lds_cap, lifo_at, narrow_at, big_env, monkeypatch):
+    """The cooperative walk's node queue (rt_coop.h): with its LDS ring capped at the minimum (RSRT_COOP_LDS_CAP=320) a batch of up to 256 rays
+    spills its newest items to the wave's arena block and takes them back — all the more when the wave never turns to newest-first
+    (RSRT_COOP_LIFO_AT=3072; 0: it always pops newest first, the first version of the walk); with RSRT_COOP_NARROW_AT small a wave pops ONE
+    item a trip whenever more than that many items are outstanding (0: always — a plain depth-first walk of the whole batch).  Which items
+    travel together, and in which order, must be invisible: suzanne and the 15 k-triangle grid, reduced frames, bit for bit against the oracle,
+    and the probe."""
     import sys
     sys.path.insert(0, util.ROOT + "/tools")
     import make_big_scene
     if lds_cap:
         monkeypatch.setenv("RSRT_COOP_LDS_CAP", lds_cap)
+    if lifo_at:
+        monkeypatch.setenv("RSRT_COOP_LIFO_AT", lifo_at)
     if narrow_at:
         monkeypatch.setenv("RSRT_COOP_NARROW_AT", narrow_at)
     for sc, w, h, spp in [(R.Scene.load_toml(util.scene_path("suzanne")), 96, 64, 3), (R.Scene.load_toml(make_big_scene.make(4)), 120, 68, 2)]:

@@ -55,6 +55,7 @@ def rays_of(sc, rng, n_cam_w=96, n_cam_h=54, sec_per_cam=2):
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else 'grid'
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 96
+    fifo = len(sys.argv) > 3 and sys.argv[3] == 'fifo'  # node items oldest first (a queue) instead of newest first (a stack)
     sc = load(name)
     wn, _ = wide_tree(sc)
     w = wn.view(np.uint32)
@@ -83,7 +84,8 @@ def main():
                 tot['leaf_rec_slots'] += int(cnt.max()) * 64            # one record a trip
                 tot['leaf_pair_slots'] += int(((cnt + 1) // 2).max()) * 64  # two records a trip (slots in units of a PAIR trip)
                 continue
-            take = ns[-64:]; del ns[-64:]
+            if fifo: take = ns[:64]; del ns[:64]
+            else: take = ns[-64:]; del ns[-64:]
             tot['node_trips'] += 1; tot['node_items'] += len(take)
             r = np.array([t[0] for t in take]); nd = np.array([t[1] for t in take])
             a = (bmin[nd] - o[r][:, None, :]) * inv[r][:, None, :]; bb = (bmax[nd] - o[r][:, None, :]) * inv[r][:, None, :]
@@ -96,7 +98,7 @@ def main():
                     elif leaf_len[nd[j], k]: ls.append((int(r[j]), int(leaf_len[nd[j], k])))
             tot['max_ns'] = max(tot['max_ns'], len(ns)); tot['max_ls'] = max(tot['max_ls'], len(ls))
     nrays = tot['batches'] * batch
-    print('%s: %d wide nodes; %d rays in batches of %d (incoherent)' % (name, nw, nrays, batch))
+    print('%s: %d wide nodes; %d rays in batches of %d (incoherent), node items %s' % (name, nw, nrays, batch, 'oldest first' if fifo else 'newest first'))
     print('  node items / ray %.2f, node trips / batch %.1f, lanes busy %.1f %%' % (tot['node_items'] / nrays, tot['node_trips'] / tot['batches'], 100.0 * tot['node_items'] / (64 * tot['node_trips'])))
     print('  leaf items / ray %.2f, records / ray %.2f (%.2f a leaf), leaf trips / batch %.1f, lanes busy %.1f %% of the item slots' %
           (tot['leaf_items'] / nrays, tot['leaf_rec'] / nrays, tot['leaf_rec'] / max(1, tot['leaf_items']), tot['leaf_trips'] / tot['batches'], 100.0 * tot['leaf_items'] / (64 * tot['leaf_trips'])))

@@ -42,10 +42,18 @@ if tot:
     print('  wave-time shares (s_memtime, lane 0): ' + '  '.join('%s %.1f%%' % (n, 100 * c[16 + i] / tot) for i, n in enumerate(names)) +
           '  census %.1f%%  other %.1f%%' % (100 * c[22] / tot, 100 * c[21] / tot))
     print('  cycles per invocation: ' + '  '.join('%s %.0f' % (n, c[16 + i] / max(c[i], 1)) for i, n in enumerate(names)) + '  census %.0f' % (c[22] / max(sum(c[0:5]), 1)))
-if c[15] or c[28]:
+if c[25]:  # the cooperative walk (rt_coop.h): a TRACE call takes every waiting ray
+    inv = max(c[1], 1)
+    print('  cooperative walk per TRACE call: %.1f rays (slots), %.1f node trips at %.1f%% of the lanes, %.1f leaf trips at %.1f%%, %.1f record-loop trips at %.1f%% of the PAIR slots' % (
+        c[6] / inv, c[10] / inv, 100 * c[11] / max(64 * c[10], 1), c[14] / inv, 100 * c[28] / max(64 * c[14], 1), c[12] / inv, 100 * c[13] / max(128 * c[12], 1)))
+    print('    items popped: node %.1f%% of the lane slots (%.1f%% of them dropped: shadow rays already occluded), leaf %.1f%% (%.1f%% dropped)' % (
+        100 * c[30] / max(64 * c[10], 1), 100 * (1 - c[11] / max(c[30], 1)), 100 * c[29] / max(64 * c[14], 1), 100 * (1 - c[28] / max(c[29], 1))))
+    print('    wave cycles: %.0f a node trip, %.0f a leaf trip (%.0f a record-loop trip); node trips %.1f%% / leaf trips %.1f%% of the TRACE stage' % (
+        c[25] / max(c[10], 1), c[26] / max(c[14], 1), c[26] / max(c[12], 1), 100 * c[25] / max(c[17], 1), 100 * c[26] / max(c[17], 1)))
+elif c[15] or c[28]:
     inv = max(c[1], 1)
     print('  typed leaf loops per TRACE invocation: triangle trips %.2f, plane trips %.2f, sphere trips %.2f' % (c[12] / inv, c[15] / inv, c[28] / inv))
-if c[29] or c[30]:
+if (c[29] or c[30]) and not c[25]:
     tri_l = c[13] - c[29] - c[30]
     print('  flat primitive loops, lanes busy: triangles %.1f%% of %.3e wave trips, planes %.1f%% of %.3e, spheres %.1f%% of %.3e' % (
         100 * tri_l / max(64 * c[12], 1), c[12], 100 * c[29] / max(64 * c[15], 1), c[15], 100 * c[30] / max(64 * c[28], 1), c[28]))
