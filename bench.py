@@ -15,6 +15,14 @@ hand-over of the RCCL id, sums of the counters.
 metric = Mrays/s = (extension rays + issued shadow rays, counted on the device) / wall time;
 ms_per_step = ms/frame.
 
+N > 1 proves itself and cannot hang (round 4): after the timed region rank 0 renders the WHOLE frame alone into a second buffer and the
+JSON line says whether the gathered N-GPU frame equals it bit for bit (`frame_equals_1gpu`), which collective really ran, and every
+rank's trace / exchange milliseconds (`multi_gpu`); the collective bring-up (rsrt_comm_init) and the first exchange run under a watchdog
+thread that, should they not return within RSRT_BENCH_WATCHDOG_S seconds (default 120), prints rank / step / an NCCL_DEBUG hint to stderr
+and ends the process with os._exit(3) — a fresh non-zero exit, never a re-exec.  At N = 1 the line also carries `extra_configs`: the other
+BASELINE.json configs (default, cube, suzanne, the 15 k-triangle grid, sixteen back-to-back single-sample calls), 3 frames each AFTER the
+timed region, with the oracle-counted roofline fraction of each.
+
 roofline: the kernel's scene is LDS-resident and its environment MALL-resident, so HBM is not the
 roof it is under; FP32 VALU issue is.  `frac` = ALGORITHMIC lane-operations per second (the f32 / u32 operations the
 reference's integrator executes per path, counted by the oracle's counting build, x paths / launch time) / 78.64 T/s;
@@ -347,6 +355,135 @@ def roofline_object(pmc, build_id, launch_ms, paths_per_launch, per_path, owned_
     return ro
 
 
+# ---------------------------------------------------------------------------------------------- N > 1: watchdog, proof
+class watchdog:
+    """`with watchdog("comm_init", rank, step): collective()` — a timer thread beside a call that may never return (a collective some rank
+    never enters).  On expiry: one line to stderr saying who waited for what, and os._exit(3): the process ends with a fresh non-zero
+    exit code (nothing is re-executed, no exception tries to unwind through a blocked C call)."""
+
+    def __init__(self, what, rank, step, seconds=None):
+        self.what, self.rank, self.step = what, rank, step
+        self.seconds = float(os.environ.get("RSRT_BENCH_WATCHDOG_S", "120")) if seconds is None else float(seconds)
+        self.timer = None
+
+    def _expired(self):
+        sys.stderr.write("[bench] WATCHDOG: rank %d has waited %.0f s for %s (step %s) — a rank that never entered the collective, or a link that "
+                         "never came up; rerun with NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL (or RSRT_COMM_MODE=reduce / --collective torch-nccl) "
+                         "to see where.  Exiting with code 3.\n" % (self.rank, self.seconds, self.what, self.step))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        import threading
+        self.timer = threading.Timer(self.seconds, self._expired)
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
+def fault(name):
+    """Fault injection for the watchdog's test: RSRT_BENCH_FAULT=<name> makes this call never return (as a hung collective would)."""
+    if os.environ.get("RSRT_BENCH_FAULT") == name:
+        while True:
+            time.sleep(3600)
+
+
+def frame_proof(gathered, alone):
+    """Is the frame the N ranks rendered and rank 0 gathered the frame ONE GPU renders, bit for bit?  Both [H, W, 4] float32."""
+    a = np.ascontiguousarray(gathered, np.float32).view(np.uint32)
+    b = np.ascontiguousarray(alone, np.float32).view(np.uint32)
+    same = a.shape == b.shape and bool(np.array_equal(a, b))
+    out = {"frame_equals_1gpu": same}
+    if not same and a.shape == b.shape:
+        bad = (a != b).any(axis=-1)
+        ys, xs = np.nonzero(bad)
+        out["differing_pixels"] = int(bad.sum())
+        out["first_differing_pixel_xy"] = [int(xs[0]), int(ys[0])]
+    return out
+
+
+def gather_rank_stats(rank, world, trace_ms, reduce_ms, dist=None):
+    """Every rank's kernel / exchange milliseconds per frame, on every rank (torch.distributed all_gather_object; world 1: this rank's)."""
+    mine = {"rank": rank, "trace_ms": trace_ms, "reduce_ms": reduce_ms}
+    if world == 1 or dist is None:
+        return [mine]
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return sorted(out, key=lambda r: r["rank"])
+
+
+# ---------------------------------------------------------------------------------------------- the other BASELINE configs
+EXTRA_CONFIGS = [  # (label, scene, width, height, spp, bounces, calls per frame)
+    ("config 2: default.toml 1280x720 64 spp 10 bounces", "default", 1280, 720, 64, 10, 1),
+    ("config 3: cube.toml 1280x720 128 spp 10 bounces", "cube", 1280, 720, 128, 10, 1),
+    ("config 3b: suzanne.toml 1280x720 128 spp 10 bounces (968 triangles: general-BVH walk)", "suzanne", 1280, 720, 128, 10, 1),
+    ("config 3c: suzanne grid 4x4 1280x720 32 spp 10 bounces (15,488 triangles: general-BVH walk)", "grid4", 1280, 720, 32, 10, 1),
+    ("interactive: house.toml 1920x1080, 16 back-to-back single-sample calls (State::render), 8 bounces", "house", 1920, 1080, 16, 8, 16),
+]
+
+
+def extra_configs(env, device_index, log, frames=3):
+    """The BASELINE.json configs the headline line does not carry, each timed for `frames` frames after the timed region (N = 1 only):
+    ms per frame, Mrays/s and the oracle-counted roofline fraction (f32 + u32 operations per path counted by liboracle_ops.so on sample 0 of
+    a quarter-scale frame — a per-path average — x paths per frame / frame time / 78.64 T/s)."""
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import util
+    import rsoderh_raytracing_amd as R
+    out = []
+    peak = N_SIMD * LANES_PER_SIMD_CYCLE * MAX_CLOCK_HZ / 1e12
+    for label, scene, w, h, spp, mb, calls in EXTRA_CONFIGS:
+        try:
+            if scene.startswith("grid"):
+                import make_big_scene
+                path = make_big_scene.make(int(scene[4:]))
+            else:
+                path = scene_path(scene)
+            sc = R.Scene.load_toml(path)
+            st = R.State.new(sc, env, w, h, device=device_index)
+            st.max_bounces = mb
+
+            def frame():
+                st.clear()
+                if calls == 1:
+                    st.render_range(0, spp)
+                else:
+                    for k in range(calls):
+                        st.render_range(k * (spp // calls), spp // calls)
+
+            frame()
+            st.synchronize()
+            st.stats()
+            t = time.perf_counter()
+            for _ in range(frames):
+                frame()
+            st.synchronize()
+            dt = (time.perf_counter() - t) / frames
+            g = st.stats()
+            st.close()
+            rays, paths = (g["ext_rays"] + g["shadow_rays"]) / frames, g["paths"] / frames
+            _, c = oracle.render(util.oracle_scene(sc), util.oracle_env(env), sc.camera_uniform().view(oracle.CAMERA), w // 4, h // 4, 0, 1, mb,
+                                 flags=oracle.FLAG_ANYHIT_SHADOW, n_threads=effective_cores(), fast="ops")
+            ops = (c["f32_ops"] + c["int_ops"]) / c["paths"]
+            achieved = ops * paths / dt / 1e12
+            row = {"workload": label, "ms_per_frame": dt * 1e3, "mrays_s": rays / dt / 1e6, "rays_per_frame": rays, "kernel_ms_per_frame": g["trace_kernel_ms"] / frames,
+                   "roofline": {"bound": "valu", "frac": achieved / peak, "achieved": achieved, "peak": peak, "unit": "T lane-operations/s",
+                                "ops_per_path": ops, "counted_on": "sample 0 of a %dx%d frame (liboracle_ops.so)" % (w // 4, h // 4)}}
+            if calls > 1:
+                row["ms_per_call"] = dt * 1e3 / calls
+            out.append(row)
+            log("extra config: %-90s %8.2f ms/frame %8.0f Mrays/s frac %.3f" % (label, dt * 1e3, rays / dt / 1e6, achieved / peak))
+        except Exception as e:  # noqa: BLE001  (a config that cannot run must not cost the headline line)
+            out.append({"workload": label, "error": str(e).splitlines()[0][:200]})
+            log("extra config %s failed: %s" % (label, e))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -359,6 +496,7 @@ def main():
     ap.add_argument("--scene", default="house")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not start rocprofv3 (the committed counters are used if they match the library)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="N = 1: do not time the other BASELINE configs after the timed region")
     ap.add_argument("--collective", default="rccl", choices=["rccl", "torch-nccl", "gloo"],
                     help="rccl: rsrt_comm_reduce inside librsrt (the product path); torch-nccl: torch.distributed's reduce; "
                          "gloo: host reduce (rehearsal of N > 1 on one GPU)")
@@ -374,6 +512,7 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL between processes needs dmabuf IPC on this driver
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (before the first HIP call: the pipelined single-sample calls of extra_configs want their lanes on queues of their own)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -441,7 +580,9 @@ def main():
             ok = torch.tensor([1 if uid[0] is not None else 0], dtype=torch.int32)
             if uid[0] is not None:
                 try:
-                    state.comm_init(rank, world, uid[0])  # collective: every rank has the id, so every rank calls it
+                    with watchdog("rsrt_comm_init (ncclCommInitRank)", rank, "bring-up"):
+                        fault("hang_init")
+                        state.comm_init(rank, world, uid[0])  # collective: every rank has the id, so every rank calls it
                 except R.RsrtError as e:
                     ok[0], err = 0, str(e)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -489,6 +630,11 @@ def main():
         torch.cuda.synchronize()
 
     with torch.cuda.stream(stream):
+        if world > 1:  # the first exchange ever, under the watchdog: one untimed frame (not one of the --warmup steps)
+            with watchdog("the first exchange (%s)" % collective, rank, "first frame"):
+                fault("hang_reduce")
+                step()
+                fence()
         for _ in range(args.warmup):
             step()
         fence()
@@ -507,11 +653,20 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax[0].item())
     rays_total, paths_total = float(tot[0].item()), float(tot[1].item())
+    per_rank = gather_rank_stats(rank, world, s["trace_kernel_ms"] / args.steps, s["reduce_ms"] / args.steps, dist if world > 1 else None)
 
     result = None
     if rank == 0:
         frame = acc.cpu().numpy()
         assert np.isfinite(frame).all() and np.all(frame[..., 3] == 1.0), "frame incomplete"
+        proof = None
+        if world > 1:  # the proof: the same frame by ONE GPU (this one, partition 0 of 1, a second buffer), compared bit for bit
+            alone = R.State.new(scene, env, W, H, device=device_index)
+            alone.max_bounces = args.bounces
+            alone.render_range(0, spp)
+            proof = frame_proof(frame, alone.download())
+            alone.close()
+            log("N = %d frame equals the 1-GPU frame bit for bit: %s" % (world, proof["frame_equals_1gpu"]))
         value = rays_total / elapsed / 1e6
         launches_trace = args.steps * max(1, (s["launches"] // 2) // args.steps)
         trace_ms_per_launch = s["trace_kernel_ms"] / launches_trace
@@ -561,6 +716,15 @@ def main():
                   "kernel_ms_per_frame": {"trace": float(tmax[1].item()) / args.steps, "resolve": s["resolve_kernel_ms"] / args.steps,
                                           "reduce": float(tmax[2].item()) / args.steps},
                   "roofline": roofline, "cpu_baseline": cpu_base}
+        if world > 1:
+            result["frame_equals_1gpu"] = proof["frame_equals_1gpu"]
+            result["multi_gpu"] = {"collective": collective, "collective_note": {"rccl": "librsrt rsrt_comm_reduce: grouped ncclSend / ncclRecv gather of compact tile buffers (RSRT_COMM_MODE=reduce: dense ncclReduce)",
+                                                                                  "torch-nccl": "torch.distributed reduce (fallback: librsrt's communicator did not come up)",
+                                                                                  "gloo": "host reduce over gloo (rehearsal)"}[collective],
+                                   "comm_mode_env": os.environ.get("RSRT_COMM_MODE", ""), "per_rank": per_rank, "proof": proof,
+                                   "proof_how": "rank 0 rendered the whole frame alone (partition 0 of 1, second buffer) after the timed region; uint32 views compared"}
+        elif std_cfg and not args.no_extra_configs:
+            result["extra_configs"] = extra_configs(env, device_index, log)
     state.close()
     if world > 1:
         dist.barrier()

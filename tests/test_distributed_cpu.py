@@ -124,3 +124,71 @@ def test_owner_map_covers_every_pixel_once():
     owner = partition.tile_owner_map(1920, 1080, 8)[::16, ::16]
     counts = np.bincount(owner.ravel(), minlength=8)
     assert counts.sum() == tx * ty and counts.max() - counts.min() <= ty
+
+
+def _bench_worker(rank, world, port, full_path, out_path, corrupt):
+    """bench.py's N > 1 bookkeeping over gloo, with the frame the ranks would have rendered supplied by the test: the gathered frame is proved
+    against the one-process frame, every rank's milliseconds reach rank 0."""
+    sys.path.insert(0, util.ROOT)
+    import json
+    import bench
+    from rsoderh_raytracing_amd import partition
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = np.load(full_path)
+    h, w = full.shape[:2]
+    mine = np.full_like(full, np.nan)
+    m = partition.owned_mask(w, h, rank, world)
+    mine[m] = full[m]
+    if corrupt and rank == world - 1:  # one rank renders one of ITS pixels wrongly: the proof must say so
+        ys, xs = np.nonzero(m)
+        mine[ys[0], xs[0], 0] += 1.0
+    with bench.watchdog("the first exchange (gloo)", rank, "first frame", seconds=60):
+        bench.fault("hang_reduce")
+        frame = partition.gather_tiles(mine, rank, world)
+    stats = bench.gather_rank_stats(rank, world, 10.0 + rank, 0.5 * rank, dist)
+    if rank == 0:
+        proof = bench.frame_proof(frame, full)
+        with open(out_path, "w") as f:
+            json.dump({"proof": proof, "per_rank": stats}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_bench_multi_gpu_proof_and_rank_stats_over_gloo(tmp_path, corrupt):
+    """What `bench.py --gpus N` adds to its JSON line for N > 1 (`frame_equals_1gpu`, `multi_gpu.per_rank`, `multi_gpu.proof`), computed by
+    bench.py's own functions in a world of two over gloo: true for the real gather, false — with the pixel named — when a rank's tile is wrong."""
+    import json
+    rng = np.random.default_rng(4)
+    full = rng.uniform(0, 4, (40, 72, 4)).astype(np.float32)
+    full[..., 3] = 1.0
+    full_path, out_path = str(tmp_path / "full.npy"), str(tmp_path / "out.json")
+    np.save(full_path, full)
+    port = 33500 + (os.getpid() % 2000) + int(corrupt)
+    mp.spawn(_bench_worker, args=(2, port, full_path, out_path, corrupt), nprocs=2, join=True)
+    with open(out_path) as f:
+        out = json.load(f)
+    assert out["proof"]["frame_equals_1gpu"] is (not corrupt)
+    if corrupt:
+        assert out["proof"]["differing_pixels"] == 1 and len(out["proof"]["first_differing_pixel_xy"]) == 2
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1]
+    assert [r["trace_ms"] for r in out["per_rank"]] == [10.0, 11.0] and [r["reduce_ms"] for r in out["per_rank"]] == [0.0, 0.5]
+
+
+@pytest.mark.parametrize("where", ["hang_init", "hang_reduce"])
+def test_bench_watchdog_ends_a_hung_collective_with_exit_code_3(where):
+    """A collective that never returns (fault injection: RSRT_BENCH_FAULT) must not run into the driver's timeout with nothing written: the
+    watchdog thread prints who waited for what and ends the process with os._exit(3)."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "with bench.watchdog('rsrt_comm_init (ncclCommInitRank)' if %r == 'hang_init' else 'the first exchange (rccl)', 1, 'bring-up'):\n"
+            "    bench.fault(%r)\n"
+            "print('returned')\n" % (util.ROOT, where, where))
+    env = dict(os.environ, RSRT_BENCH_FAULT=where, RSRT_BENCH_WATCHDOG_S="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "returned" not in r.stdout
+    assert "WATCHDOG: rank 1" in r.stderr and "NCCL_DEBUG" in r.stderr and ("comm_init" in r.stderr if where == "hang_init" else "first exchange" in r.stderr)
+    # ... and without the fault the guarded call simply returns
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSRT_BENCH_WATCHDOG_S="30"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "returned" in r.stdout

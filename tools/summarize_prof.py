@@ -24,6 +24,7 @@ def load(name):
 print("== bench line under rocprofv3 --kernel-trace --stats (3 frames, no counters) ==")
 try:
     b = load("bench_under_rocprof.json")
+    print("library build %s (rsrt_build_id of the library this run timed)" % b["roofline"]["build_id"])
     print(json.dumps({k: b[k] for k in ("metric", "value", "unit", "ms_per_step", "kernel_ms_per_frame", "config")}))
 except Exception as e:  # noqa: BLE001
     print("no bench line:", e)
