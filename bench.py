@@ -288,7 +288,18 @@ def roofline_object(pmc, build_id, launch_ms, paths_per_launch, per_path, owned_
                             "note": "the flat loop tests every leaf box for every ray (flat_loop_leaf_boxes_per_ray) where the reference's walk visits "
                                     "reference_walk_nodes_per_ray nodes: more box tests, bought for full lanes; that difference, the scheduler, and div / sqrt / "
                                     "transcendentals costing several instructions each are what `overhead` holds"}})
-    shares_file = os.path.join(ROOT, "profiles", "r03_house_stage_shares.json")
+    ledger_file = os.path.join(ROOT, "profiles", "r04_house_ledger.json")
+    if counts is not None and counts.get("f32_ops") and os.path.exists(ledger_file):  # where the retired lane-instructions go, by cause (tools/ledger.py)
+        with open(ledger_file) as f:
+            lg = json.load(f)
+        ro["overhead_ledger"] = {"lane_instructions_per_ray": lg["ledger_lane_instructions_per_ray"], "share": lg["ledger_share"],
+                                 "counter_total_lane_instructions_per_ray": lg["counter_total_lane_instructions_per_ray"], "ablations": lg["ablations"],
+                                 "trace_loops": lg["trace_loops"], "taken_on_build": lg["bench_build_id"], "workload": lg["workload"], "how": lg["how"],
+                                 "reading": "no cause beyond the algorithmic operations holds much more than a tenth of what the kernel retires: IEEE forms 10 %, the flat loop's "
+                                            "extra boxes 8 %, the scheduler 10 % (VALU; 12 % of the wave time), 16 % not attributed — the flat kernel is declared done at frac 0.24"}
+    shares_file = os.path.join(ROOT, "profiles", "r04_house_stage_shares.json")
+    if not os.path.exists(shares_file):
+        shares_file = os.path.join(ROOT, "profiles", "r03_house_stage_shares.json")
     if counts is not None and counts.get("f32_ops") and os.path.exists(shares_file):  # what the non-algorithmic share consists of (instrumented build)
         with open(shares_file) as f:
             sh = json.load(f)

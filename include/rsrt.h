@@ -292,6 +292,9 @@ rsrt_status rsrt_wide_tree_build(const rsrt_primitive_info *primitives, uint32_t
 /* Diagnostic words of an instrumented build (-DRT_INSTRUMENT: loop-trip counters behind
  * tools/simd_efficiency.py); all zero in the product build. Cumulative since context creation. */
 rsrt_status rsrt_get_debug_counters(rsrt_context *ctx, uint64_t out[32]);
+/* ... and the lanes that passed each region mark (rt_math.h RT_MARK; tools/ledger.py sets them against the regions' instruction counts).
+ * Read and reset; all zero in the product build. */
+rsrt_status rsrt_get_region_counters(rsrt_context *ctx, uint64_t out[32]);
 
 /* Exhaustive device self-test of the numeric contract's one shortcut: the 3-instruction reciprocal used for
  * 1/x (rt_math.h, rt_rcp) against the compiler's correctly rounded division, over all 2^32 f32 bit patterns

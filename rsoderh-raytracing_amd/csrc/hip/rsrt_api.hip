@@ -2269,6 +2269,21 @@ rsrt_status rsrt_get_debug_counters(rsrt_context *ctx, uint64_t out[32])
     return RSRT_OK;
 }
 
+rsrt_status rsrt_get_region_counters(rsrt_context *ctx, uint64_t out[32])
+{
+    if (!ctx || !out) return RSRT_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    for (int i = 0; i < 32; i++) out[i] = 0;
+#ifdef RT_INSTRUMENT
+    { rsrt_status st0 = sync_all(ctx); if (st0) return st0; }
+    unsigned long long h[32], z[32] = {0};
+    HIP_TRY(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(rt_region_lanes), sizeof h));
+    HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(rt_region_lanes), z, sizeof z));
+    for (int i = 0; i < 32; i++) out[i] = h[i];
+#endif
+    return RSRT_OK;
+}
+
 rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, const float *dirs, uint32_t mode, uint32_t flags,
                            rsrt_hit *out)
 {

@@ -327,6 +327,7 @@ RT_DEV Surface resolve_hit(const View &S, const Hit &h, V3 o, V3 d)
     s.point = madd(d, h.t, o);
     V3 p0 = v3(r0.x, r0.y, r0.z);
     if (type == PRIM_TRIANGLE) {
+        RT_MARK2(8);
         uint32_t tri = as_u(hit_record(S, h, 1).w);
         float4 a = S.trin(3u * tri), b = S.trin(3u * tri + 1u), c = S.trin(3u * tri + 2u);
         V3 n0 = v3(a.x, a.y, a.z), n1 = v3(a.w, b.x, b.y), n2 = v3(b.z, b.w, c.x);
@@ -334,17 +335,20 @@ RT_DEV Surface resolve_hit(const View &S, const Hit &h, V3 o, V3 d)
         if (dot(n, d) > 0.0f) n = n * -1.0f;
         s.normal = n;
     } else if (type == PRIM_SPHERE) {
+        RT_MARK2(9);
         float r2 = hit_record(S, h, 1).y;
         V3 n = normalize(s.point - p0);
         V3 co = p0 - o;
         if (dot(co, co) - r2 < 1.0e-6f) n = n * -1.0f;
         s.normal = n;
     } else {
+        RT_MARK2(10);
         float4 r1 = hit_record(S, h, 1);
         V3 n = v3(r1.x, r1.y, r1.z);
         if (dot(o, n) < 0.0f) n = n * -1.0f; // origin NOT plane-relative, shader.wgsl:394
         s.normal = n;
     }
+    RT_MARK2(11);
     return s;
 }
 
@@ -774,10 +778,12 @@ RT_DEV BsdfSample bsdf_sample_in_frame(V3 ray_dir, V3 n, const Frame &frame, V3 
     V3 wi;
     float s = random_uniform(rng);
     if (s < m.diff_prob) {
+        RT_MARK2(12);
         float s0 = s / fmax_(m.diff_prob, 1.e-6f);
         float s1 = random_uniform(rng);
         wi = sample_cosine_hemisphere(s0, s1);
     } else {
+        RT_MARK2(13);
         float s0 = (s - m.diff_prob) / fmax_(m.spec_prob, 1.e-6f);
         float s1 = random_uniform(rng);
         V3 h = sample_ggx_visible_half_vector(s0, s1, wo, m.alpha);
@@ -785,6 +791,7 @@ RT_DEV BsdfSample bsdf_sample_in_frame(V3 ray_dir, V3 n, const Frame &frame, V3 
         wi = i - (2.0f * dot(h, i)) * h; // reflect(-wo, h)
         if (wi.z <= 0.0f) return BsdfSample{v3(1, 0, 0), v3(1, 0, 0), 0.0f};
     }
+    RT_MARK2(14);
     V3 scattering;
     float pdf;
     bsdf_eval_pdf_local(wo, wi, m, scattering, pdf);
@@ -1151,6 +1158,7 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
 {
     // cur != 0: a ray whose triangle loop was cut short by the vote below comes back with the triangles it has not
     // tested yet (`rem`) and its best hit so far (`h`); it needs no box test.  A batch of such rays only skips the loop.
+    RT_MARK(4);
     const bool resumed = cur != 0u;
     uint32_t all_lo = 0u, all_hi = 0u;
     const uint32_t n_leaves = __ballot(!resumed) != 0ull ? sc.n_leaves : 0u; // (wave-uniform)
@@ -1173,6 +1181,7 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
 #pragma unroll 4 // ( -1.3 % against 1 with the 1024-thread workgroups; it measured the same with 256-thread ones)
     for (uint32_t L = 0; L < n_leaves; L++) {
         if (!((active >> L) & 1u)) continue; // (wave-uniform)
+        RT_MARK(5);
         DBG_WAVE_TICK(10);
         DBG_ADD(11, 1);
         const float4 n0 = S.flat(2u * L), n1 = S.flat(2u * L + 1u);
@@ -1185,6 +1194,7 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
         all_lo |= miss ? 0u : as_u(n0.w); // .w: the leaf's records as a 64-bit mask
         all_hi |= miss ? 0u : as_u(n1.w);
     }
+    RT_MARK(6);
     const unsigned long long all_m = resumed ? rem : (((unsigned long long)all_hi << 32) | all_lo);
     const unsigned long long tri_all = ((unsigned long long)sc.tri_mask_hi << 32) | sc.tri_mask_lo;
     const unsigned long long pl_all = ((unsigned long long)sc.plane_mask_hi << 32) | sc.plane_mask_lo;
@@ -1203,8 +1213,9 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
     // Two triangles per trip: both records are requested together and the two tests are independent instruction streams
     // until their results are taken in (in record order, so that the any-hit exit sees the same first hit)
     while (tri_m != 0ull) {
+        RT_MARK(7);
         DBG_WAVE_TICK(12);
-        DBG_ADD(13, 1);
+        DBG_ADD(13, 1); DBG_ADD(25, 1); // (25: lane-trips of the pair loop, for tools/ledger.py)
         const uint32_t rec_a = (uint32_t)__builtin_ctzll(tri_m);
         tri_m &= tri_m - 1ull;
         const bool two = tri_m != 0ull;
@@ -1230,8 +1241,10 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
         if (stop) tri_m = pl_m = sp_m = 0ull;
         if ((uint32_t)__popcll(__ballot(tri_m != 0ull)) * 100u < tri_started * quorum) break; // wave-uniform (quorum 0: never)
     }
+    RT_MARK(8);
     const unsigned long long tri_left = tri_m; // (the planes and spheres of a ray that is cut short are still tested in this call)
     while (pl_m != 0ull) {
+        RT_MARK(9);
         DBG_WAVE_TICK(15);
         DBG_ADD(13, 1); DBG_ADD(29, 1);
         const uint32_t rec = (uint32_t)__builtin_ctzll(pl_m);
@@ -1241,7 +1254,9 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
         RT_FLAT_ACCEPT(t, rec)
         if (better & anyhit) pl_m = sp_m = 0ull;
     }
+    RT_MARK(8);
     while (sp_m != 0ull) {
+        RT_MARK(10);
         DBG_WAVE_TICK(28);
         DBG_ADD(13, 1); DBG_ADD(30, 1);
         const uint32_t rec = (uint32_t)__builtin_ctzll(sp_m);
@@ -1252,6 +1267,7 @@ RT_DEV void trace_flat(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 d, V
         if (better & anyhit) sp_m = 0ull;
     }
 #undef RT_FLAT_ACCEPT
+    RT_MARK(13);
     rem = (anyhit & (h.t < RT_INFINITY)) ? 0ull : tri_left; // any hit ends a shadow ray, whatever it still holds
     cur = rem != 0ull ? 1u : RT_END;
 }
@@ -1732,6 +1748,7 @@ RT_DEV void trace_dispatch(DBG_DECL const View &S, const DevScene &sc, V3 o, V3 
         if (finite == 0.0f) {
             trace_flat(DBG_ARG S, sc, o, d, inv, anyhit, quorum, cur, flat_rem, h, coherent);
         } else {
+            RT_MARK_COLD();
             trace_threaded(DBG_ARG S, sc.n_nodes, o, d, prune, anyhit, 0xffffffffu, cur, h, work);
         }
     } else if (TRAV == 3) {

@@ -30,6 +30,31 @@
 
 #define RT_DEV __device__ __forceinline__
 
+// Region marks for the overhead ledger (tools/ledger.py).  Nothing in the product build.  -DRT_LEDGER (an analysis build that is
+// only disassembled, never run): two s_nop in a row mark the border of a code region, so that the VALU instructions of each region can be
+// counted in the disassembly.  -DRT_INSTRUMENT (librsrt_instr.so): the lanes that pass a mark are counted (one atomic per wave and mark:
+// rsrt_get_region_counters) — static instructions x lanes = lane-instructions by region.  RT_MARK_COLD: the entry of a path that next to no
+// lane takes (the full division behind the exact reciprocal, the tree-walk fallback of axis-parallel rays): the count of a region stops there.
+#if defined(RT_LEDGER)
+#define RT_MARK(k) asm volatile("s_nop 11\n\ts_nop " #k ::: "memory")
+#define RT_MARK2(k) asm volatile("s_nop 12\n\ts_nop " #k ::: "memory")
+#define RT_MARK_COLD() asm volatile("s_nop 13\n\ts_nop 0" ::: "memory")
+#elif defined(RT_INSTRUMENT)
+__device__ unsigned long long rt_region_lanes[32];
+#define RT_MARK_N(i)                                                                                                                          \
+    do {                                                                                                                                      \
+        const unsigned long long m_ = __ballot(true);                                                                                         \
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m_)) atomicAdd(&rt_region_lanes[i], (unsigned long long)__popcll(m_));           \
+    } while (0)
+#define RT_MARK(k) RT_MARK_N(k)
+#define RT_MARK2(k) RT_MARK_N(16 + (k))
+#define RT_MARK_COLD() do { } while (0)
+#else
+#define RT_MARK(k) do { } while (0)
+#define RT_MARK2(k) do { } while (0)
+#define RT_MARK_COLD() do { } while (0)
+#endif
+
 struct V3 {
     float x, y, z;
 };
@@ -75,7 +100,7 @@ RT_DEV uint32_t as_u(float f) { return __float_as_uint(f); }
 // compiler's full division; the empty asm keeps that path a branch instead of a select of both.
 RT_DEV float rt_rcp(float x)
 {
-#ifdef RT_FAST_NUMERICS
+#if defined(RT_FAST_NUMERICS) || defined(RT_FAST_RCP) // (RT_FAST_RCP: the ledger's ablation build, tools/r04_ledger.sh — what the exact reciprocal costs beyond v_rcp_f32)
     return __builtin_amdgcn_rcpf(x);
 #endif
     const uint32_t ex = (as_u(x) >> 23) & 0xffu;
@@ -85,6 +110,7 @@ RT_DEV float rt_rcp(float x)
         return __builtin_fmaf(e, r0, r0);
     }
     asm volatile("; rt_rcp: full division");
+    RT_MARK_COLD();
     return 1.0f / x;
 }
 
@@ -100,11 +126,12 @@ RT_DEV float rt_rcp_short(float x)
 }
 RT_DEV V3 rt_rcp3(V3 d)
 {
-#ifdef RT_FAST_NUMERICS
+#if defined(RT_FAST_NUMERICS) || defined(RT_FAST_RCP)
     return V3{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
 #endif
     if (rt_rcp_short_ok(d.x) & rt_rcp_short_ok(d.y) & rt_rcp_short_ok(d.z)) return V3{rt_rcp_short(d.x), rt_rcp_short(d.y), rt_rcp_short(d.z)};
     asm volatile("; rt_rcp3: full division");
+    RT_MARK_COLD();
     return V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
 }
 

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         // every stage: the kernel stays within 128 registers without scratch memory, tests/test_code_object.py)
         uint32_t lane = lane0;
         if (kCoop) asm volatile("" : "+v"(lane));
+        RT_MARK(0);
         DBG_STAMP(21); // previous stage's tail is charged below; this resets the clock for the census
         // ---------------- 1. census of the stage tags (each lane looks at its kSlotsPerLane slots)
         uint32_t tags[L::kSlotsPerLane];
@@ -304,9 +305,11 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         (void)dbg_stage;
         if (lane == 0) { DBG_ADD(dbg_stage, 1); DBG_ADD(5 + dbg_stage, (kCoop && best == ST_TRACE) ? best_n : n_run); }
         DBG_STAMP(22); // census + compaction
+        RT_MARK(1);
 
         if (best == ST_GEN) {
             // ---------------- GEN: hand out (pixel, sample) items of the wave's chunk
+            RT_MARK(2);
             uint32_t given = 0; // lanes [given, n_run) still need an item
             bool started = false; // this lane has built a camera ray
             V3 cam_o = v3(0.0f, 0.0f, 0.0f), cam_d = v3(0.0f, 0.0f, 0.0f);
@@ -359,7 +362,9 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             }
             // the camera rays are traced here and now: the lanes are all busy, the rays of a tile are coherent, and the
             // path's first trip through the scheduler (a sixth of all its stage switches) is saved
+            RT_MARK(3);
             if (kGenTrace && started) trace_slot(slot, (uint32_t)F_EXT | (uint32_t)TAG_TRACE, cam_o, cam_d, true);
+            RT_MARK(14);
             if (exhausted) { // nothing more to hand out: park every FREE slot
                 for (uint32_t k = 0; k < L::kSlotsPerLane; k++)
                     if (lane + 64u * k < POOL && TAG_OF(lane + 64u * k) == TAG_FREE) SET_TAG(lane + 64u * k, TAG_IDLE);
@@ -401,6 +406,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         } else if (best == ST_TRACE) {
             // ---------------- TRACE: one ray of the slot from its vertex O — the shadow ray (direction S, any
             // hit) while one is pending, else the extension ray (direction E, closest hit): cast_ray_bvh
+            RT_MARK(12);
             if (on) {
                 const uint32_t ct = CT_OF(slot);
                 const uint32_t dcol = (ct & F_SHADOW) ? (uint32_t)H_SX : (uint32_t)H_EX;
@@ -410,6 +416,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             }
         } else if (best == ST_MISS) {
             // ---------------- MISS: brute-force fallback of cast_ray (shader.wgsl:583-598), then escape
+            RT_MARK2(0);
             if (on) {
                 const uint32_t ct = CT_OF(slot);
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
@@ -432,15 +439,18 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 Hit h;
                 h.t = RT_INFINITY; h.ref = 0; h.src = SRC_BVH; h.u = h.v = 0.0f;
                 for (uint32_t i = 0; i < sc.n_spheres; i++) {
+                    RT_MARK2(1);
                     float u, v;
                     float t = test_record(S, i, SRC_FB_SPHERE, o, d, u, v);
                     if (t >= 0.0f && t < h.t) { h.t = t; h.ref = i; h.src = SRC_FB_SPHERE; }
                 }
                 for (uint32_t i = 0; i < sc.n_planes; i++) {
+                    RT_MARK2(2);
                     float u, v;
                     float t = test_record(S, i, SRC_FB_PLANE, o, d, u, v);
                     if (t >= 0.0f && t < h.t) { h.t = t; h.ref = i; h.src = SRC_FB_PLANE; }
                 }
+                RT_MARK2(3);
                 if (h.did_hit()) { // SHADE takes it from here (and settles the pending NEE term)
                     if (kCoop) BEST_T(slot) = as_u(h.t); else SETH(kTCell, slot, h.t);
                     if (kCoop) {
@@ -465,6 +475,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             }
         } else if (best == ST_SHADE) {
             // ---------------- SHADE: one whole iteration of trace_ray's loop body at a hit (shader.wgsl:1233-1299)
+            RT_MARK2(4);
             if (on) {
                 const uint32_t ct = CT_OF(slot);
                 const V3 o = v3(HOTF(H_OX, slot), HOTF(H_OY, slot), HOTF(H_OZ, slot));
@@ -525,6 +536,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 const V3 wo = to_frame_local(frame, -d);
                 V3 nee = v3(0.0f, 0.0f, 0.0f);
                 if (want_shadow) { // what :1247-1249 adds if the shadow ray comes back unoccluded
+                    RT_MARK2(5);
                     DBG_WAVE_TICK(23); DBG_ADD(24, 1);
                     const V3 wi = to_frame_local(frame, es.direction);
                     V3 scattering;
@@ -533,8 +545,10 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                     const float w = power_heuristic(es.pdf, pdf_bsdf);
                     nee = T * w * es.radiance * scattering * cos_nee / es.pdf;
                 }
+                RT_MARK2(6);
                 SHADE_STAMP(13);
                 const BsdfSample bs = bsdf_sample_in_frame(d, surf.normal, frame, wo, mat, rng);
+                RT_MARK2(15);
                 SHADE_STAMP(14);
                 bool finished = false, nee_counts = want_shadow;
                 if (bs.dir.x == 0.0f && bs.dir.y == 0.0f && bs.dir.z == 0.0f) {
@@ -571,6 +585,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             }
         } else {
             // ---------------- FINISH: the path ended at its last vertex; its shadow ray is back
+            RT_MARK2(7);
             if (on) {
                 const uint32_t ct = CT_OF(slot);
                 V3 Lr = v3(COLDF(C_LX, slot), COLDF(C_LY, slot), COLDF(C_LZ, slot));
@@ -579,6 +594,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 SET_TAG(slot, TAG_FREE);
             }
         }
+        RT_MARK(15);
         RT_WAVE_HANDOVER(); // tags, hot and cold columns: the next census / stage reads them from other lanes
         DBG_STAMP(16 + dbg_stage); // the stage just run
     }
@@ -596,6 +612,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
 #undef COLDF
 #undef SETC
 
+    RT_MARK(11);
     unsigned long long n_work64 = n_work;
     for (int off = 32; off > 0; off >>= 1) {
         n_paths += __shfl_down(n_paths, off);

@@ -22,7 +22,7 @@ FLAG_PRUNE = 2                # opt-in t-pruning; NOT exactly result-preserving 
 _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "rsrt_upload_scene",
             "rsrt_upload_environment", "rsrt_set_partition", "rsrt_accumulator_resize", "rsrt_accumulator_bind",
             "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_debug_view_f16", "rsrt_render",
-            "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters", "rsrt_display_srgb8",
+            "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters", "rsrt_get_region_counters", "rsrt_display_srgb8",
             "rsrt_selftest_numerics", "rsrt_build_id", "rsrt_wide_tree_build", "rsrt_build_bvh_device",
             "rsrt_partition_owner", "rsrt_partition_mask", "rsrt_partition_tiles", "rsrt_comm_available", "rsrt_comm_unique_id", "rsrt_comm_init", "rsrt_comm_reduce", "rsrt_comm_destroy",
             "rsrt_multi_create", "rsrt_multi_destroy", "rsrt_multi_last_error", "rsrt_multi_size", "rsrt_multi_context",
@@ -86,6 +86,7 @@ def lib():
         L.rsrt_synchronize.argtypes = [C.c_void_p]
         L.rsrt_get_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.rsrt_get_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.rsrt_get_region_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.rsrt_selftest_numerics.argtypes = [C.c_void_p, C.c_void_p]
         L.rsrt_cast_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.rsrt_partition_owner.restype = C.c_uint32
@@ -306,6 +307,12 @@ class State:
     def debug_counters(self):
         out = np.zeros(32, np.uint64)
         self._check(self._L.rsrt_get_debug_counters(self._ctx, _p(out)), "rsrt_get_debug_counters")
+        return out
+
+    def region_counters(self):
+        """Lanes that passed each region mark since the last call (instrumented build; zeros in the product build)."""
+        out = np.zeros(32, np.uint64)
+        self._check(self._L.rsrt_get_region_counters(self._ctx, _p(out)), "rsrt_get_region_counters")
         return out
 
     def selftest_numerics(self):

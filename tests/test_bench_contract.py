@@ -149,3 +149,20 @@ def test_committed_r04_profiles_were_taken_on_the_committed_kernel_sources():
                 stale.append(os.path.basename(csv_path))
     if stale:  # (as for the PMC file above: bench.py measures live; a stale profile is a to-do, not a defect of the code under test)
         pytest.skip("taken on other kernel sources than the committed ones: %s — re-run tools/r04_profiles.sh on the GPU box" % ", ".join(stale))
+
+
+def test_overhead_ledger_adds_up_to_the_counters():
+    """profiles/r04_house_ledger.json (tools/ledger.py): the causes, the unattributed rest included, add up to the hardware counters'
+    lane-instructions per ray, at least four fifths of them are attributed, and bench.py hangs the ledger on the roofline object."""
+    with open(os.path.join(util.ROOT, "profiles", "r04_house_ledger.json")) as f:
+        lg = json.load(f)
+    total = lg["counter_total_lane_instructions_per_ray"]
+    causes = lg["ledger_lane_instructions_per_ray"]
+    assert abs(sum(causes.values()) / total - 1.0) < 1e-9 and 1500 < total < 1800
+    rest = next(v for k, v in causes.items() if k.startswith("not attributed"))
+    assert 0.0 <= rest / total < 0.2
+    assert abs(total / lg["counter_total_of_the_256spp_bench_run"] - 1.0) < 0.02  # the 64-spp ablation frame and the 256-spp bench frame agree
+    a = lg["ablations"]
+    assert a["product"]["lane_instructions_per_ray"] > a["b93b1a04be"]["lane_instructions_per_ray"] > a["402bff4434"]["lane_instructions_per_ray"]
+    ro = bench.roofline_object(None, "0123456789abcdef", 98.0, 1920 * 1080 * 256, 3450.0, 1920 * 1080, 256, house_counts())
+    assert abs(sum(ro["overhead_ledger"]["share"].values()) - 1.0) < 1e-9 and "declared done" in ro["overhead_ledger"]["reading"]

@@ -14,8 +14,10 @@ scene = sys.argv[3] if len(sys.argv) > 3 else 'house'
 sc = R.Scene.load_toml(scene if scene.endswith('.toml') else util.scene_path(scene))
 w, h, mb = (int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (1920, 1080, 8)
 st = R.State.new(sc, env, w, h); st.max_bounces = mb
+st.region_counters()  # (reset)
 st.render_range(0, spp); st.synchronize()
 g = st.stats(); c = st.debug_counters().astype(np.float64)
+regions = [float(x) for x in st.region_counters()]
 names = ['GEN', 'TRACE', 'MISS', 'SHADE', 'FINISH']
 print(os.path.basename(scene), ' '.join('%s=%s' % kv for kv in sorted(os.environ.items()) if kv[0].startswith('RSRT_')), 'trace kernel %.1f ms' % g['trace_kernel_ms'], 'rays', g['ext_rays'] + g['shadow_rays'],
       'traversal steps/ray %.1f' % (g['traversal_steps'] / (g['ext_rays'] + g['shadow_rays'])))
@@ -37,12 +39,13 @@ if tot:  # also as a file: bench.py attaches it to the roofline object's `overhe
     with open(os.path.join(ROOT, 'gpurun_out', 'stage_shares_%s.json' % os.path.basename(scene).replace('.toml', '')), 'w') as f:
         json.dump({'workload': '%s %dx%d %d spp %d bounces' % (os.path.basename(scene), w, h, spp, mb), 'build_id': S.build_id(),
                    'wave_time_shares': shares, 'stage_lanes_of_64': {n: (c[5 + i] / c[i] if c[i] else None) for i, n in enumerate(names)},
+                   'counters': [float(x) for x in c], 'region_lanes': regions, 'rays': float(rays), 'paths': float(g['paths']), 'n_spheres': int(len(sc.spheres)), 'n_planes': int(len(sc.planes)),
                    'source': 'tools/simd_efficiency.py: instrumented build (librsrt_instr.so), s_memtime stamps of lane 0 between the stages'}, f, indent=1)
 if tot:
     print('  wave-time shares (s_memtime, lane 0): ' + '  '.join('%s %.1f%%' % (n, 100 * c[16 + i] / tot) for i, n in enumerate(names)) +
           '  census %.1f%%  other %.1f%%' % (100 * c[22] / tot, 100 * c[21] / tot))
     print('  cycles per invocation: ' + '  '.join('%s %.0f' % (n, c[16 + i] / max(c[i], 1)) for i, n in enumerate(names)) + '  census %.0f' % (c[22] / max(sum(c[0:5]), 1)))
-if c[25]:  # the cooperative walk (rt_coop.h): a TRACE call takes every waiting ray
+if c[14] and c[25]:  # the cooperative walk (rt_coop.h): a TRACE call takes every waiting ray
     inv = max(c[1], 1)
     print('  cooperative walk per TRACE call: %.1f rays (slots), %.1f node trips at %.1f%% of the lanes, %.1f leaf trips at %.1f%%, %.1f record-loop trips at %.1f%% of the PAIR slots' % (
         c[6] / inv, c[10] / inv, 100 * c[11] / max(64 * c[10], 1), c[14] / inv, 100 * c[28] / max(64 * c[14], 1), c[12] / inv, 100 * c[13] / max(128 * c[12], 1)))
@@ -53,7 +56,7 @@ if c[25]:  # the cooperative walk (rt_coop.h): a TRACE call takes every waiting 
 elif c[15] or c[28]:
     inv = max(c[1], 1)
     print('  typed leaf loops per TRACE invocation: triangle trips %.2f, plane trips %.2f, sphere trips %.2f' % (c[12] / inv, c[15] / inv, c[28] / inv))
-if (c[29] or c[30]) and not c[25]:
+if (c[29] or c[30]) and not (c[14] and c[25]):
     tri_l = c[13] - c[29] - c[30]
     print('  flat primitive loops, lanes busy: triangles %.1f%% of %.3e wave trips, planes %.1f%% of %.3e, spheres %.1f%% of %.3e' % (
         100 * tri_l / max(64 * c[12], 1), c[12], 100 * c[29] / max(64 * c[15], 1), c[15], 100 * c[30] / max(64 * c[28], 1), c[28]))
