@@ -55,7 +55,6 @@ struct RenderParams {
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
     uint32_t trace_budget, descend_quorum, flat_quorum, stop_quorum;
     uint32_t coop_lds_cap, coop_lifo_at, coop_narrow_at; // cooperative walk (rt_coop.h): node-queue entries kept in LDS, outstanding items at which a wave pops newest first / one item a trip
-    uint32_t coop_defer; // ... and its TRACE stage waits while another stage has at least this many slots to run (rt_wavepool.h, "which stage")
     uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
     float *sample_buf;
     unsigned int *work_counter;
@@ -712,7 +711,6 @@ struct rsrt_context {
     int blocks_per_cu[21][RT_N_VARIANTS] = {}; // [scene view * 7 + traversal][kernel variant]
     int kernel_variant = 4; // index into kVariantPool
     int max_traversal = 6; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
-    uint32_t coop_defer = 40; // RSRT_COOP_DEFER
     uint32_t coop_lds_cap = RT_COOP_NCAP, coop_lifo_at = RT_COOP_LIFO_AT, coop_narrow_at = RT_COOP_NARROW_AT; // RSRT_COOP_LDS_CAP / _LIFO_AT / _NARROW_AT (tests: force the node queue's spill / newest-first / one-item trips)
     bool allow_flat = true;
     bool allow_hybrid = true;
@@ -1267,7 +1265,6 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     if (const char *pb = getenv("RSRT_PIPE_BLOCKS")) { int v = atoi(pb); if (v >= 1 && v <= 4) ctx->pipe_blocks = v; } // experiment knob
     if (const char *o = getenv("RSRT_BLOCKS_PER_CU")) { int v = atoi(o); if (v > 0) ctx->max_blocks_per_cu = v; } // experiment knob
     if (const char *pr = getenv("RSRT_PROBE_REPEAT")) { int v = atoi(pr); if (v > 1 && v <= 4096) ctx->probe_repeat = (uint32_t)v; }
-    if (const char *cd = getenv("RSRT_COOP_DEFER")) { int v = atoi(cd); if (v >= 0 && v <= 65) ctx->coop_defer = (uint32_t)v; }
     if (const char *cl = getenv("RSRT_COOP_LDS_CAP")) { int v = atoi(cl); if (v >= (int)RT_COOP_MIN_LDS_CAP && v <= (int)RT_COOP_NCAP) ctx->coop_lds_cap = (uint32_t)v; }
     if (const char *cf = getenv("RSRT_COOP_LIFO_AT")) { int v = atoi(cf); if (v >= 0 && v <= (int)RT_COOP_NARROW_AT) ctx->coop_lifo_at = (uint32_t)v; }
     if (const char *cn = getenv("RSRT_COOP_NARROW_AT")) { int v = atoi(cn); if (v >= 0 && v <= (int)RT_COOP_NARROW_AT) ctx->coop_narrow_at = (uint32_t)v; }
@@ -2124,7 +2121,6 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.coop_lds_cap = ctx->coop_lds_cap;
     P.coop_lifo_at = ctx->coop_lifo_at;
     P.coop_narrow_at = ctx->coop_narrow_at;
-    P.coop_defer = ctx->coop_defer;
     // a small job behind a kernel that is still running: the 256-thread form, one workgroup per CU, on one of four lanes (see Lane)
     bool pipelined = false;
     if (ctx->overlap && kv == 4 && sv == 1 && trav != 6 && (uint64_t)P.n_slots * sample_count <= ctx->small_paths && sample_count <= pass_samples)

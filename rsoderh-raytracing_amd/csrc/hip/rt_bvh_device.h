@@ -40,7 +40,10 @@ struct BvhNodeB { // breadth-first build node
 };
 struct BvhTask { uint32_t begin, end, node; };
 
-// monotone float <-> uint key, for min / max reductions with integer atomics in LDS
+// monotone float <-> uint key, for min / max reductions with integer atomics in LDS.  (-0 orders below +0 here, so a bound that is a zero comes
+// out as -0 from a min and +0 from a max whatever the operand order; the host's std::fmin / fmax — like the reference's f32::min / max — may return
+// either zero.  The one exception to "the same tree bit for bit": the SIGN of a zero bound; same values, and no slab test can tell them apart.
+// tests/test_bvh_device.py builds a scene with +0 / -0 vertices on a symmetry plane.)
 RT_DEV uint32_t bvh_key(float f) { const uint32_t b = as_u(f); return (b >> 31) ? ~b : (b | 0x80000000u); }
 RT_DEV float bvh_unkey(uint32_t k) { return as_f((k >> 31) ? (k & 0x7fffffffu) : ~k); }
 

@@ -277,16 +277,6 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
         uint32_t best = ST_COUNT, best_n = 0;
         for (uint32_t s = 0; s < ST_COUNT; s++)
             if (count[s] >= best_n && count[s] > 0) { best = s; best_n = count[s]; }
-        if (kCoop && P.coop_defer != 0u && count[ST_TRACE] > 0u) {
-            // The cooperative walk takes EVERY waiting ray at once and keeps its lanes busy whatever their number — but each call ends with a
-            // tail of thin trips, so the more rays a call, the better; the other stages run one slot a lane and want full batches.  So TRACE
-            // waits while some other stage has at least P.coop_defer slots to run (0: plain "fullest stage first", A/B)
-            uint32_t ob = ST_COUNT, on_ = 0u;
-            for (uint32_t s = 0; s < ST_COUNT; s++)
-                if (s != ST_TRACE && count[s] >= on_ && count[s] > 0u) { ob = s; on_ = count[s]; }
-            if (ob == ST_COUNT || on_ < P.coop_defer) { best = ST_TRACE; best_n = count[ST_TRACE]; }
-            else { best = ob; best_n = on_; }
-        }
         if (best == ST_COUNT) break; // nothing left anywhere
         // ---------------- 3. compaction: dense list of the chosen stage's slots
         uint32_t base = 0;

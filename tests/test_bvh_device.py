@@ -96,6 +96,22 @@ def test_device_builder_equals_the_host_builder_node_for_node():
             tri[k] = rng.integers(0, len(verts), nt)
         p, n, d, _ = st.build_bvh_device(sph, pls, verts, tri)
         assert same_tree((p, n, d), host.build_bvh(sph, pls, verts, tri)), trial
+    # vertices on a symmetry plane written as 0.0 here and -0.0 there (OBJ exporters do that): min / max of (+0, -0) is either zero, by
+    # operand order on the host (std::fmin / fmax, as the reference's f32::min / max) and always (-0, +0) on the device (monotone integer keys) —
+    # the trees are the same node for node and the bounds the same VALUES; the sign bit of a zero bound may differ, and no traversal can tell
+    # (the exception to "bit-identical", stated in rt_bvh_device.h)
+    rng = np.random.default_rng(12)
+    nt = 48
+    verts = np.zeros(3 * nt, T.VEC3)
+    v = np.round(rng.uniform(-2, 2, (3 * nt, 3)) * 2) / 2
+    v[rng.random(3 * nt) < 0.5, 0] = 0.0
+    v[:, 0] = np.where((v[:, 0] == 0) & (rng.random(3 * nt) < 0.5), -0.0, v[:, 0])
+    verts["v"] = v
+    assert np.signbit(verts["v"][:, 0][verts["v"][:, 0] == 0]).any() and not np.signbit(verts["v"][:, 0][verts["v"][:, 0] == 0]).all()
+    tri = np.zeros(nt, T.TRIANGLE)
+    tri["vertex_0"], tri["vertex_1"], tri["vertex_2"] = np.arange(nt) * 3, np.arange(nt) * 3 + 1, np.arange(nt) * 3 + 2
+    p, n, d, _ = st.build_bvh_device(np.zeros(0, T.SPHERE), np.zeros(0, T.PLANE_DESC), verts, tri)
+    assert same_tree((p, n, d), host.build_bvh(np.zeros(0, T.SPHERE), np.zeros(0, T.PLANE_DESC), verts, tri))  # (values: -0.0 == 0.0)
     # a big random triangle soup: long top-level ranges (many scan chunks per workgroup), deep tree
     rng = np.random.default_rng(2)
     nt = 40000

@@ -11,7 +11,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 rm -rf "$OUT/trace"   # (a trace directory that accumulates runs was how a stale kernel_stats.csv got committed twice: one run, one set of files)
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $R/bench.py --no-pmc --no-cpu-baseline --steps 3 --warmup 1 "$@" \
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $R/bench.py --no-pmc --no-cpu-baseline --no-extra-configs --steps 3 --warmup 1 "$@" \
   > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err" || { tail -5 "$OUT/bench_under_rocprof.err"; exit 1; }
 timeout -k 10 400 python3 $R/bench.py --steps 5 --warmup 2 --write-profile "$@" > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
 cp $R/profiles/pmc_house_1080p_8b.json "$OUT/" 2>/dev/null
