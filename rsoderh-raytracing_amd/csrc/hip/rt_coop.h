@@ -267,18 +267,24 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
             n_new += (uint32_t)__popcll(bi[k]);
         }
         if (st.ns_n + n_new > st.lds_cap) coop_make_room(st, n_new, lane);
+        // (each slot's push behind a wave-uniform test: near the root no lane has a leaf in any slot, near the leaves few have interior
+        // children in the later slots — the slot's prefix count, item and address are then never formed)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (((im >> k) & 1u) != 0u) st.ns[st.ring(st.ns_n + coop_lanes_below(bi[k]))] = head | (child0 + (uint32_t)k);
-            st.ns_n += (uint32_t)__popcll(bi[k]);
+            if (bi[k] != 0ull) {
+                if (((im >> k) & 1u) != 0u) st.ns[st.ring(st.ns_n + coop_lanes_below(bi[k]))] = head | (child0 + (uint32_t)k);
+                st.ns_n += (uint32_t)__popcll(bi[k]);
+            }
         }
         // ---- ... and the hit leaves: one item each, first record and count (a leaf's records are a run of its node's)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t m = ((hm >> k) & 1u) != 0u ? as_u(n[4 + k].w) : 0u;
             const unsigned long long bl = __ballot(m != 0u);
-            if (m != 0u) st.ls[st.ls_n + coop_lanes_below(bl)] = head | ((rec_base + (uint32_t)__builtin_ctz(m)) << 3) | ((uint32_t)__popc(m) - 1u);
-            st.ls_n += (uint32_t)__popcll(bl);
+            if (bl != 0ull) {
+                if (m != 0u) st.ls[st.ls_n + coop_lanes_below(bl)] = head | ((rec_base + (uint32_t)__builtin_ctz(m)) << 3) | ((uint32_t)__popc(m) - 1u);
+                st.ls_n += (uint32_t)__popcll(bl);
+            }
         }
         COOP_STAMP(25);
     }
