@@ -263,8 +263,9 @@ rsrt_status rsrt_get_stats(rsrt_context *ctx, rsrt_stats *out);
  * mode bit 0: 0 = cast_ray (BVH, then the brute-force fallback), 1 = cast_ray_bvh only;
  * mode bits 1-3, the traversal: 0 = threaded tree walk, 1 = the first kernel's stack walk, 2 = tree walk with typed leaf
  *   loops, 3 = flat loop over the leaf boxes (house, default, cube in production), 4 = fixed-order walk with ties
- *   decided by tabulated visiting ranks (suzanne and anything bigger in production) — the very device functions
- *   rt_render_pool_kernel's TRACE stage calls; a scene that does not qualify for 2 / 3 / 4 is RSRT_ERR_INVALID_ARGUMENT;
+ *   decided by tabulated visiting ranks, 5 = wide walk (4-wide nodes, one ray a lane), 6 = cooperative wide walk (the same
+ *   nodes; a wave's rays as (ray, node) / (ray, leaf) work items: suzanne and anything bigger in production) — the very device
+ *   functions rt_render_pool_kernel's TRACE stage calls; a scene that does not qualify is RSRT_ERR_INVALID_ARGUMENT;
  * mode bit 4: read the scene from LDS exactly as the production kernel stages it for that traversal (whole image, or
  *   for mid-size scenes the nodes + escape links / the pre-order nodes) instead of from global memory.  Host pointers. */
 typedef struct rsrt_hit {

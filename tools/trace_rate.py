@@ -5,6 +5,7 @@ directions about the normal (two generations), plus rays from the same points to
 Run under rocprofv3 --kernel-trace --stats (tools/trace_rate.sh); the kernel's average duration / the ray count is the figure.
     python tools/trace_rate.py [million rays] [repeats]"""
 import os, sys
+os.environ.setdefault('RSRT_PROBE_REPEAT', os.environ.get('TRACE_REPEAT', '32'))  # read once, by rsrt_context_create
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
@@ -49,7 +50,7 @@ O = np.concatenate([p1, p2, p1])[:n]; D = np.concatenate([d1, d2, ds])[:n]
 perm = rng.permutation(len(O)); O, D = np.ascontiguousarray(O[perm]), np.ascontiguousarray(D[perm])
 print('rays %d: %d first-bounce, %d second-bounce, %d towards the sun; camera rays that hit: %.0f%%' % (len(O), len(p1), len(p2), len(p1), 100 * hit.mean()), flush=True)
 REPEAT = int(os.environ.get('TRACE_REPEAT', '32'))
-os.environ['RSRT_PROBE_REPEAT'] = str(REPEAT)  # read by rsrt_cast_rays at each call
+# (RSRT_PROBE_REPEAT is read when the context is created: set at the top of this script)
 for _ in range(reps):
     h = st.cast_rays(O, D, MODE)
 print('hit fraction of the secondary set %.2f' % (h['did_hit'] != 0).mean())
