@@ -56,8 +56,10 @@ LANES_PER_SIMD_CYCLE = 32.0  # wave64 VALU instruction = 2 cycles on a SIMD32 (g
 MAX_CLOCK_HZ = 2.4e9
 LDS_ARRAY_CYCLES_PER_CU_CYCLE = 1.0
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_house_1080p_8b.json")
-# NO TA_* / TD_* counters in any pass: a rocprofv3 --pmc run with them hung on this pool and cost a 15-minute GPU call (round 2; the
-# profiler's counter set, not a kernel of ours — avoided, not root-caused).  tools/pmc_scene.sh passes its extra lists through here.
+# NO TA_* / TD_* counters in any pass: a rocprofv3 --pmc run with them hung on this pool and cost a 15-minute GPU call (round 2).  AVOIDED, NOT
+# ROOT-CAUSED: the killed call merged no file back (gpurun_out/ holds nothing of it — checked again in round 4), so which dispatch was in flight,
+# and whether the render kernel itself had finished, is not on record; all that is known is that the same kernel, frame and rocprofv3 passes without
+# those counters have completed in every one of the ~60 PMC runs since.  tools/pmc_scene.sh passes its extra lists through here and refuses them too.
 PMC_PASSES = [  # pass 0 is what `utilisation` needs; the others are reported when they succeed
     ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
      "SQ_BUSY_CYCLES", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"],

@@ -28,7 +28,7 @@ for n in ns:
     ok = bool(np.array_equal(util.bits(img), util.bits(ref))) and (g['ext_rays'], g['shadow_rays']) == (ost['ext_rays'], ost['shadow_rays'])
     print('  240x135 x 2 spp vs oracle (%.1f s): bit-exact %s, rays %d, traversal steps / ray %.1f' % (time.time() - t, ok, g['ext_rays'] + g['shadow_rays'], g['traversal_steps'] / max(1, g['ext_rays'] + g['shadow_rays'])), flush=True)
     # rate
-    for trav in ('4', '3'):
+    for trav in ('6', '5', '3'):
         os.environ['RSRT_TRAVERSAL'] = trav
         st = R.State.new(sc, env, 1280, 720); st.max_bounces = 10
         st.render_range(0, 8); st.synchronize(); st.stats()
