@@ -165,6 +165,103 @@ def test_cpu_restatement_of_the_wide_walk_finds_the_oracles_hits(name, path):
     assert total / n < 40  # a quarter of the binary walk's box steps, roughly
 
 
+def coop_walk(wn, o, d, single, rng, fifo=True, chunk=64):
+    """The cooperative wide walk (csrc/hip/rt_coop.h) for a BATCH of rays, restated: a list of (ray, node) items and a list of (ray, first record,
+    count) items, `chunk` items a trip in the order the kernel would take them (oldest node items first, or newest) — or, with `rng`, in ANY order;
+    results folded as min over (t bits << 32 | record), a second record at the same closest t raises the ray's tie flag.
+    single[rec][ray] = that record's hit distance or < 0.  Returns (best key per ray or None, tie flags, node items, records tested)."""
+    w = wn.view(np.uint32)
+    n = len(o)
+    with np.errstate(divide="ignore"):
+        inv = (np.float32(1.0) / d).astype(np.float32)
+    best, tie = [None] * n, [False] * n
+    nodes, leaves = [(r, 0) for r in range(n)], []
+    n_items = n_rec = 0
+    while nodes or leaves:
+        if len(leaves) >= chunk or not nodes:
+            take, leaves = leaves[-chunk:], leaves[:-chunk]
+            for r, first, cnt in take:
+                for rec in range(first, first + cnt):
+                    n_rec += 1
+                    t = single[rec][r]
+                    if t >= 0:
+                        key = (int(np.float32(t).view(np.uint32)) << 32) | rec
+                        if best[r] is not None and (best[r] >> 32) == (key >> 32) and best[r] != key:
+                            tie[r] = True  # (the atomic that comes second meets the cell of the first)
+                        if best[r] is None or key < best[r]:
+                            best[r] = key
+            continue
+        if rng is not None:
+            rng.shuffle(nodes)
+        take, nodes = (nodes[:chunk], nodes[chunk:]) if fifo else (nodes[-chunk:], nodes[:-chunk])
+        for r, cur in take:
+            n_items += 1
+            wa, base = int(w[cur, 0, 3]), int(w[cur, 1, 3])
+            for k in range(4):
+                a = (wn[cur, 2 * k, :3] - o[r]) * inv[r]
+                b = (wn[cur, 2 * k + 1, :3] - o[r]) * inv[r]
+                t0 = max(np.float32(0), np.minimum(a, b).max())
+                t1 = np.maximum(a, b).min()
+                if t0 > t1:
+                    continue
+                if (wa >> 26) >> k & 1:
+                    nodes.append((r, (wa & 0x3FFFFFF) + k))
+                else:
+                    m = int(w[cur, 4 + k, 3])
+                    if m:
+                        leaves.append((r, base + (m & -m).bit_length() - 1, bin(m).count("1")))
+    return best, tie, n_items, n_rec
+
+
+@pytest.mark.parametrize("name,path", [s for s in scenes() if s[0] in ("default", "suzanne")])
+def test_cpu_restatement_of_the_cooperative_walk(name, path):
+    """What rt_coop.h rests on, without a GPU: the result of a batch does not depend on the order in which its items are taken (oldest first,
+    newest first, shuffled), it is the oracle's closest hit whenever no second record shares the closest t, and whenever one does the tie flag is
+    up (those rays go through the exact fixed-order walk once more on the device)."""
+    sc = R.Scene.load_toml(path)
+    wn, oon = wide_tree(sc)
+    osc = util.oracle_scene(sc)
+    rng = np.random.default_rng(17)
+    n = 192
+    o = (rng.uniform(-3, 3, (n, 3)) + [0, 1, 1]).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o[:8], d[:8] = o[8:16], d[8:16]  # (a few rays twice: items of equal rays side by side)
+    ref = oracle.cast_rays(osc, o, d, 1, 0)
+    single_old = {}
+    for old in range(len(sc.primitives)):
+        nodes1 = np.zeros(1, sc.bvh_nodes.dtype)
+        nodes1["bounds_min"][0, :3] = -1e30
+        nodes1["bounds_max"][0, :3] = 1e30
+        nodes1["primitives_or_second_child_index"], nodes1["primitives_len"] = old, 1
+        one = oracle.Scene(materials=osc.materials, spheres=osc.spheres, planes=osc.planes, vertices=osc.vertices, normals=osc.normals,
+                           triangles=osc.triangles, prims=osc.prims, nodes=nodes1.view(oracle.BVH_NODE))
+        h = oracle.cast_rays(one, o, d, 1, 0)
+        single_old[old] = np.where(h["did_hit"] != 0, h["distance"], np.float32(-1))
+    single = {rec: single_old[int(oon[rec])] for rec in range(len(sc.primitives))}
+    runs = [coop_walk(wn, o, d, single, None, fifo=True), coop_walk(wn, o, d, single, None, fifo=False), coop_walk(wn, o, d, single, np.random.default_rng(5), chunk=7)]
+    assert runs[0][0] == runs[1][0] == runs[2][0]  # the same (t, record) whatever the order ...
+    assert runs[0][2] == runs[1][2] == runs[2][2] and runs[0][3] == runs[1][3] == runs[2][3]  # ... from the same items
+    best, tie = runs[0][0], runs[0][1]
+    for i in range(n):
+        t_all = sorted(float(single[rec][i]) for rec in range(len(sc.primitives)) if single[rec][i] >= 0)
+        if ref["did_hit"][i]:
+            assert best[i] is not None and np.uint32(best[i] >> 32).view(np.float32) == ref["distance"][i], i
+            shared = len(t_all) > 1 and t_all[0] == t_all[1]
+            if shared:  # the closest t is shared: the flag is up in ANY order (the atomic that comes second sees the first) ...
+                assert all(r[1][i] for r in runs), i
+            elif len(set(t_all)) == len(t_all):  # ... and without two records at one t it never is (a tie behind the closest hit may raise it, harmlessly, by order)
+                assert not any(r[1][i] for r in runs), i
+            if not shared:  # the winning record is the oracle's: its material shows
+                old = int(oon[best[i] & 0xFFFFFFFF])
+                pr = sc.primitives[old]
+                mat = [sc.spheres, sc.planes, sc.triangles][min(int(pr["primitive_type"]), 2)][int(pr["index"])]["material_id"]
+                assert int(mat) == int(ref["material_id"][i]), i
+        else:
+            assert best[i] is None
+    assert runs[0][2] / n < 16
+
+
 def test_trees_that_do_not_qualify_are_refused():
     sc = R.Scene.load_toml(util.scene_path("default"))
     nodes = sc.bvh_nodes.copy()
