@@ -80,6 +80,7 @@ struct CoopStacks {
     uint32_t ns_h, ns_n;    // the ring's head (oldest item) and fill
     uint32_t ls_n, gs_n;
     uint32_t lds_cap, lifo_at, narrow_at;
+    uint32_t leaf_quorum; // a leaf trip hands its stragglers back once fewer than this percentage of the wave's lanes still hold records (0: never)
     RT_DEV uint32_t ring(uint32_t i) const // the ring's i-th entry, counted from the head (i < 2 * RT_COOP_NCAP - head)
     {
         const uint32_t k = ns_h + i;
@@ -165,12 +166,27 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
             uint32_t rec = (item >> 3) & (RT_COOP_MAX_RECORDS - 1u);
             // a shadow ray that is already occluded needs nothing more (any hit: only did_hit is read)
             uint32_t left = (act0 & !(shadow & anyhit_shadow & ((ct & CF_OCCLUDED) != 0u))) ? (item & 7u) + 1u : 0u;
-            work += left;
+            const uint32_t n_started = (uint32_t)__popcll(__ballot(left != 0u));
             DBG_ADD(28, left != 0u ? 1 : 0); DBG_ADD(29, act0 ? 1 : 0);
-            while (left != 0u) {
+            // (a wave-uniform loop: every lane stays until the wave is through, so that the stack's fill — a scalar — is only ever changed by
+            // all lanes together; a lane without records sits the trips out)
+            for (;;) {
+                const unsigned long long more = __ballot(left != 0u);
+                if (more == 0ull) break;
+                // Leaves hold 1-5 records (a fifth of them five): the third pair trip would run for a fifth of the lanes.  Once fewer than
+                // leaf_quorum percent of the lanes that came in with records still hold some, what they hold goes back on the stack as items of
+                // its own — to be tested in a later, fuller trip — and this trip ends.  (Never before the first pair trip: an item shrinks each
+                // time round; a lane's leftover is part of one leaf: the stack's bound stands.)
+                if ((uint32_t)__popcll(more) * 100u < n_started * st.leaf_quorum) {
+                    if (left != 0u) st.ls[st.ls_n + coop_lanes_below(more)] = (item & RT_COOP_HEAD) | (rec << 3) | (left - 1u);
+                    st.ls_n += (uint32_t)__popcll(more);
+                    break;
+                }
+                if (left == 0u) continue;
                 DBG_WAVE_TICK(12);
                 DBG_ADD(13, left >= 2u ? 2 : 1);
                 const bool two = left >= 2u;
+                work += two ? 2u : 1u;
                 const uint32_t rec_a = rec, rec_b = two ? rec + 1u : rec;
                 float4 ra[3], rb[3];
                 S.template prim_rec<3>(rec_a, ra);
@@ -317,6 +333,7 @@ RT_DEV void coop_slow_rays(DBG_DECL const View &S, const DevScene &sc, uint32_t 
         Hit h;
         h.t = RT_INFINITY; h.ref = 0u; h.src = SRC_BVH; h.u = h.v = 0.0f;
         uint32_t cur = job != 0u ? 0u : RT_END;
+        if (job != 0u) { RT_MARK(4); } // (diagnostic build: how many rays come here — region counter 4, which only the flat kernel uses otherwise)
         trace_preorder(DBG_ARG S, sc, o, d, false, shadow & anyhit_shadow, 0xffffffffu, 0u, cur, h, nullptr, work);
         if (job != 0u) {
             if (shadow) {

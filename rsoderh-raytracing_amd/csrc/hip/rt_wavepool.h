@@ -366,7 +366,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 CoopStacks cs;
                 cs.ns = list + L::kListDwords; cs.ls = list; cs.gs = G + L::kColdColumns * POOL;
                 cs.ns_h = cs.ns_n = cs.ls_n = cs.gs_n = 0u;
-                cs.lds_cap = P.coop_lds_cap; cs.lifo_at = P.coop_lifo_at; cs.narrow_at = P.coop_narrow_at;
+                cs.lds_cap = P.coop_lds_cap; cs.lifo_at = P.coop_lifo_at; cs.narrow_at = P.coop_narrow_at; cs.leaf_quorum = P.coop_leaf_quorum;
                 for (uint32_t i0 = 0; i0 < best_n; i0 += 64u) { // (the list is read to the end before the first leaf item lands in the same words)
                     const bool valid = i0 + lane < best_n;
                     const uint32_t s = list[valid ? i0 + lane : 0u];

@@ -51,6 +51,7 @@ if c[14] and c[25]:  # the cooperative walk (rt_coop.h): a TRACE call takes ever
         c[6] / inv, c[10] / inv, 100 * c[11] / max(64 * c[10], 1), c[14] / inv, 100 * c[28] / max(64 * c[14], 1), c[12] / inv, 100 * c[13] / max(128 * c[12], 1)))
     print('    items popped: node %.1f%% of the lane slots (%.1f%% of them dropped: shadow rays already occluded), leaf %.1f%% (%.1f%% dropped)' % (
         100 * c[30] / max(64 * c[10], 1), 100 * (1 - c[11] / max(c[30], 1)), 100 * c[29] / max(64 * c[14], 1), 100 * (1 - c[28] / max(c[29], 1))))
+    print('    rays handed to the exact fixed-order walk (equal closest t, or a non-finite 1/d): %d of %d (%.4f %%)' % (regions[4], rays, 100.0 * regions[4] / max(rays, 1)))
     print('    wave cycles: %.0f a node trip, %.0f a leaf trip (%.0f a record-loop trip); node trips %.1f%% / leaf trips %.1f%% of the TRACE stage' % (
         c[25] / max(c[10], 1), c[26] / max(c[14], 1), c[26] / max(c[12], 1), 100 * c[25] / max(c[17], 1), 100 * c[26] / max(c[17], 1)))
 elif c[15] or c[28]:
