@@ -45,7 +45,7 @@ if tot:
     print('  wave-time shares (s_memtime, lane 0): ' + '  '.join('%s %.1f%%' % (n, 100 * c[16 + i] / tot) for i, n in enumerate(names)) +
           '  census %.1f%%  other %.1f%%' % (100 * c[22] / tot, 100 * c[21] / tot))
     print('  cycles per invocation: ' + '  '.join('%s %.0f' % (n, c[16 + i] / max(c[i], 1)) for i, n in enumerate(names)) + '  census %.0f' % (c[22] / max(sum(c[0:5]), 1)))
-if c[14] and c[25]:  # the cooperative walk (rt_coop.h): a TRACE call takes every waiting ray
+if c[14] > 0.5 * c[1] and c[25]:  # the cooperative walk (rt_coop.h): a TRACE call takes every waiting ray
     inv = max(c[1], 1)
     print('  cooperative walk per TRACE call: %.1f rays (slots), %.1f node trips at %.1f%% of the lanes, %.1f leaf trips at %.1f%%, %.1f record-loop trips at %.1f%% of the PAIR slots' % (
         c[6] / inv, c[10] / inv, 100 * c[11] / max(64 * c[10], 1), c[14] / inv, 100 * c[28] / max(64 * c[14], 1), c[12] / inv, 100 * c[13] / max(128 * c[12], 1)))
@@ -57,7 +57,7 @@ if c[14] and c[25]:  # the cooperative walk (rt_coop.h): a TRACE call takes ever
 elif c[15] or c[28]:
     inv = max(c[1], 1)
     print('  typed leaf loops per TRACE invocation: triangle trips %.2f, plane trips %.2f, sphere trips %.2f' % (c[12] / inv, c[15] / inv, c[28] / inv))
-if (c[29] or c[30]) and not (c[14] and c[25]):
+if (c[29] or c[30]) and not (c[14] > 0.5 * c[1] and c[25]):
     tri_l = c[13] - c[29] - c[30]
     print('  flat primitive loops, lanes busy: triangles %.1f%% of %.3e wave trips, planes %.1f%% of %.3e, spheres %.1f%% of %.3e' % (
         100 * tri_l / max(64 * c[12], 1), c[12], 100 * c[29] / max(64 * c[15], 1), c[15], 100 * c[30] / max(64 * c[28], 1), c[28]))
