@@ -15,9 +15,10 @@ hand-over of the RCCL id, sums of the counters.
 metric = Mrays/s = (extension rays + issued shadow rays, counted on the device) / wall time;
 ms_per_step = ms/frame.
 
-N > 1 proves itself and cannot hang (round 4): after the timed region rank 0 renders the WHOLE frame alone into a second buffer and the
-JSON line says whether the gathered N-GPU frame equals it bit for bit (`frame_equals_1gpu`), which collective really ran, and every
-rank's trace / exchange milliseconds (`multi_gpu`); the collective bring-up (rsrt_comm_init) and the first exchange run under a watchdog
+N > 1 proves itself and cannot hang (round 4): after the timed region rank 0 renders the WHOLE frame alone into a second buffer BEFORE the timed
+region and every candidate exchange — librsrt's RCCL gather of compact tile buffers, its dense ncclReduce, torch's nccl reduce, gloo — must reproduce
+it bit for bit before it is timed (the first that does is used, all ranks switching together: `multi_gpu.pre_flight`); the JSON line says whether
+the last timed frame equals it too (`frame_equals_1gpu`), which exchange really ran, and every rank's trace / exchange milliseconds (`multi_gpu`); the collective bring-up (rsrt_comm_init) and the first exchange run under a watchdog
 thread that, should they not return within RSRT_BENCH_WATCHDOG_S seconds (default 120), prints rank / step / an NCCL_DEBUG hint to stderr
 and ends the process with os._exit(3) — a fresh non-zero exit, never a re-exec.  At N = 1 the line also carries `extra_configs`: the other
 BASELINE.json configs (default, cube, suzanne, the 15 k-triangle grid, sixteen back-to-back single-sample calls), 3 frames each AFTER the
@@ -419,6 +420,22 @@ def frame_proof(gathered, alone):
     return out
 
 
+def choose_exchange(candidates, attempt, agree, note=None):
+    """The first candidate exchange that is RIGHT on every rank.  attempt(name) -> bool (this rank's verdict; an exception counts as False);
+    agree(ok) -> bool: the ranks' verdicts combined (all must say yes; a collective — every rank calls it for every candidate, in the same order).
+    Returns the name, or None if none is right."""
+    for cand in candidates:
+        try:
+            ok = bool(attempt(cand))
+        except Exception as e:  # noqa: BLE001  (a mode that cannot even run is a mode that is not right)
+            ok = False
+            if note:
+                note(cand, str(e).splitlines()[0][:160] if str(e) else type(e).__name__)
+        if agree(ok):
+            return cand
+    return None
+
+
 def gather_rank_stats(rank, world, trace_ms, reduce_ms, dist=None):
     """Every rank's kernel / exchange milliseconds per frame, on every rank (torch.distributed all_gather_object; world 1: this rank's)."""
     mine = {"rank": rank, "trace_ms": trace_ms, "reduce_ms": reduce_ms}
@@ -642,12 +659,55 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    exchange_log = []  # what the pre-flight proof found, mode by mode
     with torch.cuda.stream(stream):
-        if world > 1:  # the first exchange ever, under the watchdog: one untimed frame (not one of the --warmup steps)
-            with watchdog("the first exchange (%s)" % collective, rank, "first frame"):
-                fault("hang_reduce")
-                step()
-                fence()
+        if world > 1:
+            # The first exchange ever, under the watchdog, and PROVED before anything is timed: rank 0 renders the whole frame alone once
+            # (partition 0 of 1, a second buffer) and every candidate exchange must reproduce it bit for bit — librsrt's gather of compact tile
+            # buffers first; if its frame is wrong (it has never run with N > 1 on hardware), librsrt's dense ncclReduce (rsrt_comm_set_mode);
+            # then torch's own nccl reduce; then gloo.  All ranks switch together; the timed region runs the first mode that is right.
+            alone_frame = None
+            if rank == 0:
+                alone = R.State.new(scene, env, W, H, device=device_index)
+                alone.max_bounces = args.bounces
+                alone.render_range(0, spp)
+                alone_frame = alone.download()
+                alone.close()
+            candidates = {"rccl": ["rccl", "rccl-dense-reduce", "torch-nccl", "gloo"], "torch-nccl": ["torch-nccl", "gloo"], "gloo": ["gloo"]}[collective]
+            if os.environ.get("RSRT_COMM_MODE") == "reduce" and collective == "rccl":
+                candidates = candidates[1:]
+            def attempt(cand):
+                nonlocal collective, nccl_group
+                if cand == "rccl-dense-reduce":
+                    state.comm_set_mode(True)
+                elif cand == "torch-nccl" and nccl_group is None:
+                    nccl_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", device_index))
+                collective = "rccl" if cand.startswith("rccl") else cand
+                with watchdog("the first exchange (%s)" % cand, rank, "pre-flight frame"):
+                    fault("hang_reduce")
+                    step()
+                    fence()
+                if rank != 0:
+                    return True
+                pf = frame_proof(acc.cpu().numpy(), alone_frame)
+                exchange_log.append({"exchange": cand, **pf})
+                log("pre-flight: exchange %s reproduces the 1-GPU frame bit for bit: %s" % (cand, pf["frame_equals_1gpu"]))
+                return pf["frame_equals_1gpu"]
+
+            def agree(ok):
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return int(t[0]) == 1
+
+            def note(cand, msg):
+                if rank == 0:
+                    exchange_log.append({"exchange": cand, "error": msg})
+                log("pre-flight: exchange %s failed: %s" % (cand, msg))
+
+            chosen = choose_exchange(candidates, attempt, agree, note)
+            if chosen is None:
+                raise SystemExit("no exchange reproduces the 1-GPU frame: %s" % exchange_log)
+            exchange_used = chosen
         for _ in range(args.warmup):
             step()
         fence()
@@ -673,12 +733,8 @@ def main():
         frame = acc.cpu().numpy()
         assert np.isfinite(frame).all() and np.all(frame[..., 3] == 1.0), "frame incomplete"
         proof = None
-        if world > 1:  # the proof: the same frame by ONE GPU (this one, partition 0 of 1, a second buffer), compared bit for bit
-            alone = R.State.new(scene, env, W, H, device=device_index)
-            alone.max_bounces = args.bounces
-            alone.render_range(0, spp)
-            proof = frame_proof(frame, alone.download())
-            alone.close()
+        if world > 1:  # the proof again, on the LAST timed frame: against the frame this GPU rendered alone before the timed region
+            proof = frame_proof(frame, alone_frame)
             log("N = %d frame equals the 1-GPU frame bit for bit: %s" % (world, proof["frame_equals_1gpu"]))
         value = rays_total / elapsed / 1e6
         launches_trace = args.steps * max(1, (s["launches"] // 2) // args.steps)
@@ -731,11 +787,12 @@ def main():
                   "roofline": roofline, "cpu_baseline": cpu_base}
         if world > 1:
             result["frame_equals_1gpu"] = proof["frame_equals_1gpu"]
-            result["multi_gpu"] = {"collective": collective, "collective_note": {"rccl": "librsrt rsrt_comm_reduce: grouped ncclSend / ncclRecv gather of compact tile buffers (RSRT_COMM_MODE=reduce: dense ncclReduce)",
+            result["multi_gpu"] = {"collective": collective, "exchange": exchange_used, "pre_flight": exchange_log, "collective_note": {"rccl": "librsrt rsrt_comm_reduce: grouped ncclSend / ncclRecv gather of compact tile buffers (RSRT_COMM_MODE=reduce: dense ncclReduce)",
                                                                                   "torch-nccl": "torch.distributed reduce (fallback: librsrt's communicator did not come up)",
                                                                                   "gloo": "host reduce over gloo (rehearsal)"}[collective],
                                    "comm_mode_env": os.environ.get("RSRT_COMM_MODE", ""), "per_rank": per_rank, "proof": proof,
-                                   "proof_how": "rank 0 rendered the whole frame alone (partition 0 of 1, second buffer) after the timed region; uint32 views compared"}
+                                   "proof_how": "rank 0 rendered the whole frame alone (partition 0 of 1, second buffer) before the timed region; every candidate exchange "
+                                                "had to reproduce it (pre_flight), the last timed frame is compared again; uint32 views"}
         elif std_cfg and not args.no_extra_configs:
             result["extra_configs"] = extra_configs(env, device_index, log)
     state.close()

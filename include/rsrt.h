@@ -159,8 +159,9 @@ rsrt_status rsrt_partition_tiles(uint32_t width, uint32_t height, uint32_t tile_
  * over xGMI INSIDE the library (librccl is dlopen'ed on first use; a single-GPU caller never needs it).  Every pixel has
  * exactly one owner, so that sum is a GATHER: each rank packs its tiles into the compact buffer above (1 / world of the
  * frame), the root receives world - 1 of them point to point (grouped ncclSend / ncclRecv) and scatters them into the frame;
- * nothing is added, and the N-GPU frame equals the 1-GPU frame bit for bit.  (RSRT_COMM_MODE=reduce in the environment:
- * the dense ncclReduce(sum, f32) of the full accumulators instead, for A/B.)
+ * nothing is added, and the N-GPU frame equals the 1-GPU frame bit for bit.  (RSRT_COMM_MODE=reduce in the environment when the
+ * context is created, or rsrt_comm_set_mode(ctx, 1): the dense ncclReduce(sum, f32) of the full accumulators instead — the
+ * fallback until the gather has run on a multi-GPU box; bench.py switches to it by itself if the gathered frame is not the 1-GPU frame.)
  *   rank 0:      rsrt_comm_unique_id(&id); hand the 128 bytes to the other ranks (file, socket, MPI, a torch store ...)
  *   every rank:  rsrt_comm_init(ctx, rank, world, &id)   -- creates the communicator (collective call) and sets the tile
  *                                                            partition (rank, world, current tile size)
@@ -177,6 +178,8 @@ int rsrt_comm_available(void); /* 1: librccl could be loaded (a dlopen, nothing 
 rsrt_status rsrt_comm_unique_id(rsrt_unique_id *out); /* error text: rsrt_last_error(NULL) */
 rsrt_status rsrt_comm_init(rsrt_context *ctx, uint32_t rank, uint32_t world_size, const rsrt_unique_id *id);
 rsrt_status rsrt_comm_reduce(rsrt_context *ctx, uint32_t root, void *recv_device_rgba32f, void *hip_stream);
+rsrt_status rsrt_comm_set_mode(rsrt_context *ctx, uint32_t dense_reduce); /* 0 (default; RSRT_COMM_MODE unset): gather of compact tile buffers, 1 (RSRT_COMM_MODE=reduce):
+                                                                             * dense ncclReduce(sum) of the full accumulators; every rank the same, between frames */
 rsrt_status rsrt_comm_destroy(rsrt_context *ctx); /* also done by rsrt_context_destroy */
 
 /* -- multi-GPU, form 2: one caller, a list of devices -----------------------

@@ -699,6 +699,7 @@ struct rsrt_context {
     // multi-GPU (rsrt_comm.h): this context's RCCL communicator (an ncclComm_t), NULL in a world of one
     void *comm = nullptr;
     bool comm_owned = false;
+    bool comm_dense_mode = false; // RSRT_COMM_MODE=reduce / rsrt_comm_set_mode: the exchange is a dense ncclReduce instead of the gather of compact tile buffers
     uint32_t comm_rank = 0, comm_world = 1;
     struct ReduceEvents { hipEvent_t begin, end; };
     std::vector<ReduceEvents> pending_reduce;
@@ -1271,6 +1272,7 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     if (const char *lq = getenv("RSRT_COOP_LEAF_QUORUM")) { int v = atoi(lq); if (v >= 0 && v <= 100) ctx->coop_leaf_quorum = (uint32_t)v; }
     if (const char *cf = getenv("RSRT_COOP_LIFO_AT")) { int v = atoi(cf); if (v >= 0 && v <= (int)RT_COOP_NARROW_AT) ctx->coop_lifo_at = (uint32_t)v; }
     if (const char *cn = getenv("RSRT_COOP_NARROW_AT")) { int v = atoi(cn); if (v >= 0 && v <= (int)RT_COOP_NARROW_AT) ctx->coop_narrow_at = (uint32_t)v; }
+    if (const char *cm = getenv("RSRT_COMM_MODE")) ctx->comm_dense_mode = strcmp(cm, "reduce") == 0;
     if (const char *hq = getenv("GPU_MAX_HW_QUEUES")) { int v = atoi(hq); if (v > 0) ctx->hw_queues = v; }
     for (int m = 0; m < 21; m++) (void)hipFuncSetAttribute(probe_function(m / 7, m % 7), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     char buf[256];

@@ -155,11 +155,9 @@ struct ExchangeInFlight {
     bool root = false, dense = false, begun = false;
 };
 
-bool comm_dense()
-{
-    const char *m = getenv("RSRT_COMM_MODE"); // "reduce": the dense W*H*4 ncclReduce of round 2 (A/B on a multi-GPU node)
-    return m && strcmp(m, "reduce") == 0;
-}
+// the dense W*H*4 ncclReduce of round 2 instead of the gather of compact tile buffers (RSRT_COMM_MODE=reduce, read once when the context is created;
+// rsrt_comm_set_mode switches it — the documented fallback until the gather has run on a multi-GPU box)
+bool comm_dense(const rsrt_context *ctx) { return ctx->comm_dense_mode; }
 
 // first half: pack this rank's tiles and post its RCCL calls (root: world - 1 receives; others: one send)
 rsrt_status exchange_begin(rsrt_context *ctx, uint32_t root, void *recv_device_rgba32f, hipStream_t stream, ExchangeInFlight &x)
@@ -172,7 +170,7 @@ rsrt_status exchange_begin(rsrt_context *ctx, uint32_t root, void *recv_device_r
     x.stream = stream;
     x.root = ctx->comm_rank == root;
     x.recv = (x.root && recv_device_rgba32f) ? static_cast<float4 *>(recv_device_rgba32f) : ctx->accum;
-    x.dense = comm_dense();
+    x.dense = comm_dense(ctx);
     const TileGeom tg = tile_geom(ctx);
     const size_t seg = (size_t)tg.n_slots * sizeof(float4);
     rsrt_status st = RSRT_OK;
@@ -289,6 +287,18 @@ rsrt_status rsrt_comm_unique_id(rsrt_unique_id *out)
     return RSRT_OK;
 }
 
+// 0: the gather of compact tile buffers (default), 1: the dense ncclReduce(sum) of the full accumulators.  Every rank must choose the same.
+rsrt_status rsrt_comm_set_mode(rsrt_context *ctx, uint32_t dense_reduce)
+{
+    if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
+    if (dense_reduce > 1u) return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "comm_set_mode: 0 (gather of compact tile buffers) or 1 (dense reduce)");
+    DeviceGuard g(ctx->device);
+    rsrt_status st = sync_all(ctx); // (an exchange in flight keeps its mode)
+    if (st) return st;
+    ctx->comm_dense_mode = dense_reduce != 0u;
+    return RSRT_OK;
+}
+
 rsrt_status rsrt_comm_destroy(rsrt_context *ctx)
 {
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
@@ -332,7 +342,7 @@ rsrt_status rsrt_comm_reduce(rsrt_context *ctx, uint32_t root, void *recv_device
     if (!ctx) return RSRT_ERR_INVALID_ARGUMENT;
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
     ExchangeInFlight x;
-    const bool grouped = ctx->comm && ctx->comm_world > 1 && !comm_dense(); // the root's receives must be posted together
+    const bool grouped = ctx->comm && ctx->comm_world > 1 && !comm_dense(ctx); // the root's receives must be posted together
     if (grouped && rccl().GroupStart() != ncclSuccess) return fail(ctx, RSRT_ERR_COMM, "ncclGroupStart failed");
     rsrt_status st = exchange_begin(ctx, root, recv_device_rgba32f, stream, x);
     if (grouped) {

@@ -24,7 +24,7 @@ _SYMBOLS = ["rsrt_context_create", "rsrt_context_destroy", "rsrt_last_error", "r
             "rsrt_accumulator_clear", "rsrt_accumulator_download", "rsrt_resolve_mean_f16", "rsrt_debug_view_f16", "rsrt_render",
             "rsrt_synchronize", "rsrt_get_stats", "rsrt_cast_rays", "rsrt_describe", "rsrt_get_debug_counters", "rsrt_get_region_counters", "rsrt_display_srgb8",
             "rsrt_selftest_numerics", "rsrt_build_id", "rsrt_wide_tree_build", "rsrt_build_bvh_device",
-            "rsrt_partition_owner", "rsrt_partition_mask", "rsrt_partition_tiles", "rsrt_comm_available", "rsrt_comm_unique_id", "rsrt_comm_init", "rsrt_comm_reduce", "rsrt_comm_destroy",
+            "rsrt_partition_owner", "rsrt_partition_mask", "rsrt_partition_tiles", "rsrt_comm_available", "rsrt_comm_unique_id", "rsrt_comm_init", "rsrt_comm_reduce", "rsrt_comm_set_mode", "rsrt_comm_destroy",
             "rsrt_multi_create", "rsrt_multi_destroy", "rsrt_multi_last_error", "rsrt_multi_size", "rsrt_multi_context",
             "rsrt_multi_upload_scene", "rsrt_multi_upload_environment", "rsrt_multi_resize", "rsrt_multi_clear", "rsrt_multi_render",
             "rsrt_multi_synchronize", "rsrt_multi_download", "rsrt_multi_display_srgb8", "rsrt_multi_get_stats", "rsrt_multi_uses_rccl"]
@@ -99,6 +99,7 @@ def lib():
         L.rsrt_comm_init.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.rsrt_comm_reduce.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.rsrt_comm_destroy.argtypes = [C.c_void_p]
+        L.rsrt_comm_set_mode.argtypes = [C.c_void_p, C.c_uint32]
         L.rsrt_multi_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
         L.rsrt_multi_destroy.argtypes = [C.c_void_p]
         L.rsrt_multi_last_error.restype = C.c_char_p
@@ -215,6 +216,10 @@ class State:
         """The exchange step: every rank's tiles onto `root` over RCCL (in place unless recv_ptr names a device buffer)."""
         self._check(self._L.rsrt_comm_reduce(self._ctx, root, C.c_void_p(recv_ptr) if recv_ptr else None,
                                              C.c_void_p(stream) if stream else None), "rsrt_comm_reduce")
+
+    def comm_set_mode(self, dense_reduce):
+        """False: the exchange is the gather of compact tile buffers (default); True: the dense ncclReduce of the full accumulators."""
+        self._check(self._L.rsrt_comm_set_mode(self._ctx, 1 if dense_reduce else 0), "rsrt_comm_set_mode")
 
     def comm_destroy(self):
         self._check(self._L.rsrt_comm_destroy(self._ctx), "rsrt_comm_destroy")

@@ -98,7 +98,7 @@ def test_bench_line_carries_the_other_configs_and_the_multi_gpu_proof():
     assert any("single-sample calls" in l for l in labels)
     with open(os.path.join(util.ROOT, "bench.py")) as f:
         src = f.read()
-    for key in ('result["extra_configs"]', 'result["frame_equals_1gpu"]', 'result["multi_gpu"]', '"per_rank"', '"ms_per_frame"', '"mrays_s"', '"frac"'):
+    for key in ('result["extra_configs"]', 'result["frame_equals_1gpu"]', 'result["multi_gpu"]', '"per_rank"', '"pre_flight"', '"exchange"', 'comm_set_mode', '"ms_per_frame"', '"mrays_s"', '"frac"'):
         assert key in src, key
     assert bench.frame_proof([[[1.0, 2.0, 3.0, 1.0]]], [[[1.0, 2.0, 3.0, 1.0]]]) == {"frame_equals_1gpu": True}
     bad = bench.frame_proof([[[1.0, 2.0, 3.0, 1.0]]], [[[1.0, 2.5, 3.0, 1.0]]])

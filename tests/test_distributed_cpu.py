@@ -147,10 +147,27 @@ def _bench_worker(rank, world, port, full_path, out_path, corrupt):
         bench.fault("hang_reduce")
         frame = partition.gather_tiles(mine, rank, world)
     stats = bench.gather_rank_stats(rank, world, 10.0 + rank, 0.5 * rank, dist)
+
+    # the pre-flight choice of the exchange: "a" is wrong on the last rank only, "b" cannot even run on rank 0, "c" is right everywhere
+    tried, notes = [], []
+
+    def attempt(cand):
+        tried.append(cand)
+        if cand == "b" and rank == 0:
+            raise RuntimeError("ncclGroupEnd failed: unhandled system error")
+        return not (cand == "a" and rank == world - 1)
+
+    def agree(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t[0]) == 1
+
+    chosen = bench.choose_exchange(["a", "b", "c", "d"], attempt, agree, lambda c, m: notes.append((c, m)))
+    nothing = bench.choose_exchange(["a"], attempt, agree)
     if rank == 0:
         proof = bench.frame_proof(frame, full)
         with open(out_path, "w") as f:
-            json.dump({"proof": proof, "per_rank": stats}, f)
+            json.dump({"proof": proof, "per_rank": stats, "chosen": chosen, "tried": tried, "notes": notes, "nothing": nothing}, f)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -174,6 +191,9 @@ def test_bench_multi_gpu_proof_and_rank_stats_over_gloo(tmp_path, corrupt):
         assert out["proof"]["differing_pixels"] == 1 and len(out["proof"]["first_differing_pixel_xy"]) == 2
     assert [r["rank"] for r in out["per_rank"]] == [0, 1]
     assert [r["trace_ms"] for r in out["per_rank"]] == [10.0, 11.0] and [r["reduce_ms"] for r in out["per_rank"]] == [0.0, 0.5]
+    # the exchange that is timed is the first one EVERY rank found right: not "a" (wrong on rank 1 only), not "b" (raised on rank 0), never "d"
+    assert out["chosen"] == "c" and out["tried"] == ["a", "b", "c", "a"] and out["nothing"] is None
+    assert out["notes"] == [["b", "ncclGroupEnd failed: unhandled system error"]]
 
 
 @pytest.mark.parametrize("where", ["hang_init", "hang_reduce"])

@@ -42,6 +42,7 @@ def test_comm_and_multi_entry_points_check_their_arguments_without_a_gpu():
     ident = C.create_string_buffer(128)
     assert L.rsrt_comm_init(None, 0, 1, ident) == 1
     assert L.rsrt_comm_reduce(None, 0, None, None) == 1
+    assert L.rsrt_comm_set_mode(None, 0) == 1
     assert L.rsrt_comm_destroy(None) == 1
     assert L.rsrt_comm_unique_id(None) == 1
     h = C.c_void_p()
