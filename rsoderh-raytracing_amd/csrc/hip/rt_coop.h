@@ -10,8 +10,9 @@
 //     leaf item  (ray, first record, n)    -> n primitive tests (n <= 8: one leaf of the reference's tree)
 // and the wave keeps two lists of them in LDS: a QUEUE of node items (a ring: oldest first) and a stack of leaf items.  A trip pops up to 64
 // items — one per lane, any ray — and pushes what they turn up with wave64 ballots + prefix popcounts (the compaction north_star names, at item
-// granularity).  A lane is idle only when a list holds fewer than 64 items, i.e. at the very end of a batch; there are no rounds, no votes, no
-// per-ray stack, nothing to park: every ray of the batch is finished when both lists are empty.  Node items go oldest first because that keeps
+// granularity).  A lane is idle only when a list holds fewer than 64 items, i.e. at the very end of a batch; there are no rounds, no per-ray
+// stack, nothing to park: every ray of the batch is finished when both lists are empty.  (Two wave votes keep the trips dense: a slot's push is
+// skipped when no lane has it, and a leaf trip hands its stragglers back as items of their own — see the leaf trip.)  Node items go oldest first because that keeps
 // the end of a batch short: the shallow items, whose subtrees take the most trips, are worked off while there is plenty beside them, and what is
 // left at the end are the deep ones, one trip from their leaves (newest first, the last old item's whole subtree was walked alone: 72-78 % of
 // the lanes busy in the node trips instead of 90 %, tools/coop_sim.py and profiles/r04_coop_walk.txt).  The rays live where TRACE's rays always lived, in the pool's hot LDS columns, addressed by
@@ -69,7 +70,7 @@ RT_DEV uint32_t coop_lanes_below(unsigned long long m)
 // can the walk take this ray?  1/d by the short reciprocal (exactly the IEEE quotient there, rt_math.h) and finite, origin finite
 RT_DEV bool coop_ray_ok(V3 o, V3 d)
 {
-    const bool short_ok = rt_rcp_short_ok(d.x) & rt_rcp_short_ok(d.y) & rt_rcp_short_ok(d.z);
+    const bool short_ok = ((int)rt_rcp_short_ok(d.x) & (int)rt_rcp_short_ok(d.y) & (int)rt_rcp_short_ok(d.z)) != 0;
     const float finite = ((o.x + o.y) + o.z) * 0.0f; // NaN exactly when a component is infinite or NaN (an overflowing sum only sends a ray the long way round)
     return short_ok & (finite == 0.0f);
 }

@@ -129,7 +129,7 @@ RT_DEV V3 rt_rcp3(V3 d)
 #if defined(RT_FAST_NUMERICS) || defined(RT_FAST_RCP)
     return V3{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
 #endif
-    if (rt_rcp_short_ok(d.x) & rt_rcp_short_ok(d.y) & rt_rcp_short_ok(d.z)) return V3{rt_rcp_short(d.x), rt_rcp_short(d.y), rt_rcp_short(d.z)};
+    if (((int)rt_rcp_short_ok(d.x) & (int)rt_rcp_short_ok(d.y) & (int)rt_rcp_short_ok(d.z)) != 0) return V3{rt_rcp_short(d.x), rt_rcp_short(d.y), rt_rcp_short(d.z)};
     asm volatile("; rt_rcp3: full division");
     RT_MARK_COLD();
     return V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
