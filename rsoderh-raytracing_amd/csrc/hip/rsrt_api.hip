@@ -54,7 +54,6 @@ struct RenderParams {
     uint32_t chunk_px, n_subtiles; // a chunk covers chunk_px consecutive pixels of a tile (tile_px / n_subtiles)
     uint32_t n_slots; // n_owned_tiles * tile_w * tile_h
     uint32_t trace_budget, descend_quorum, flat_quorum, stop_quorum;
-    uint32_t coop_leaf_quorum; // ... a leaf trip hands its stragglers back once fewer than this percentage of the lanes still hold records
     uint32_t coop_lds_cap, coop_lifo_at, coop_narrow_at; // cooperative walk (rt_coop.h): node-queue entries kept in LDS, outstanding items at which a wave pops newest first / one item a trip
     uint32_t *cold_state; // wave-pool kernel: global arena of the cold path-state columns
     float *sample_buf;
@@ -420,7 +419,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_kernel(DevScene sc, uin
 template <int SV>
 __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_coop_kernel(DevScene sc, uint32_t n, const float *origins, const float *dirs,
                                                                      uint32_t mode, uint32_t flags, uint32_t repeat, rsrt_hit *out, uint32_t *gstack,
-                                                                     uint32_t lds_cap, uint32_t lifo_at, uint32_t narrow_at, uint32_t leaf_quorum)
+                                                                     uint32_t lds_cap, uint32_t lifo_at, uint32_t narrow_at)
 {
     if (SV != 0) stage_scene_lds(sc);
     const typename PoolView<SV>::type S = PoolView<SV>::make(sc);
@@ -446,10 +445,10 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_cast_rays_coop_kernel(DevScene sc
         W[C::CT + lane] = (uint32_t)F_EXT | (uint32_t)TAG_TRACE;
         RT_WAVE_HANDOVER();
         CoopStacks cs;
-        cs.ls = W + C::DWORDS; cs.ns = cs.ls + RT_COOP_LCAP;
+        cs.ls = W + C::DWORDS; cs.ns = cs.ls + RT_COOP_LCAP; cs.map = reinterpret_cast<uint16_t *>(cs.ns + RT_COOP_NCAP);
         cs.gs = gstack + (size_t)(blockIdx.x * (RT_BLOCK / RT_WAVE) + wave) * RT_COOP_GCAP;
         cs.ns_h = cs.ns_n = cs.ls_n = cs.gs_n = 0u;
-        cs.lds_cap = lds_cap; cs.lifo_at = lifo_at; cs.narrow_at = narrow_at; cs.leaf_quorum = leaf_quorum;
+        cs.lds_cap = lds_cap; cs.lifo_at = lifo_at; cs.narrow_at = narrow_at;
         coop_push_rays<kPool>(W, cs, valid, lane, W[C::CT + lane], (uint32_t)F_EXT, (uint32_t)F_SHADOW);
         coop_trace<kPool>(DBG_ARG S, W, cs, false, lane, work);
         RT_WAVE_HANDOVER();
@@ -713,7 +712,6 @@ struct rsrt_context {
     int blocks_per_cu[21][RT_N_VARIANTS] = {}; // [scene view * 7 + traversal][kernel variant]
     int kernel_variant = 4; // index into kVariantPool
     int max_traversal = 6; // most specialised traversal to use where the scene allows it (rt_wavepool.h, TRAV)
-    uint32_t coop_leaf_quorum = 35; // RSRT_COOP_LEAF_QUORUM
     uint32_t coop_lds_cap = RT_COOP_NCAP, coop_lifo_at = RT_COOP_LIFO_AT, coop_narrow_at = RT_COOP_NARROW_AT; // RSRT_COOP_LDS_CAP / _LIFO_AT / _NARROW_AT (tests: force the node queue's spill / newest-first / one-item trips)
     bool allow_flat = true;
     bool allow_hybrid = true;
@@ -1269,7 +1267,6 @@ rsrt_status rsrt_context_create(int device_index, rsrt_context **out)
     if (const char *o = getenv("RSRT_BLOCKS_PER_CU")) { int v = atoi(o); if (v > 0) ctx->max_blocks_per_cu = v; } // experiment knob
     if (const char *pr = getenv("RSRT_PROBE_REPEAT")) { int v = atoi(pr); if (v > 1 && v <= 4096) ctx->probe_repeat = (uint32_t)v; }
     if (const char *cl = getenv("RSRT_COOP_LDS_CAP")) { int v = atoi(cl); if (v >= (int)RT_COOP_MIN_LDS_CAP && v <= (int)RT_COOP_NCAP) ctx->coop_lds_cap = (uint32_t)v; }
-    if (const char *lq = getenv("RSRT_COOP_LEAF_QUORUM")) { int v = atoi(lq); if (v >= 0 && v <= 100) ctx->coop_leaf_quorum = (uint32_t)v; }
     if (const char *cf = getenv("RSRT_COOP_LIFO_AT")) { int v = atoi(cf); if (v >= 0 && v <= (int)RT_COOP_NARROW_AT) ctx->coop_lifo_at = (uint32_t)v; }
     if (const char *cn = getenv("RSRT_COOP_NARROW_AT")) { int v = atoi(cn); if (v >= 0 && v <= (int)RT_COOP_NARROW_AT) ctx->coop_narrow_at = (uint32_t)v; }
     if (const char *cm = getenv("RSRT_COMM_MODE")) ctx->comm_dense_mode = strcmp(cm, "reduce") == 0;
@@ -2125,7 +2122,6 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     P.trace_budget = ctx->trace_budget ? ctx->trace_budget : (trav >= 4 ? 4u : (trav == 3 ? 6u : 12u)); // (wide walk: rounds, not steps)
     P.coop_lds_cap = ctx->coop_lds_cap;
     P.coop_lifo_at = ctx->coop_lifo_at;
-    P.coop_leaf_quorum = ctx->coop_leaf_quorum;
     P.coop_narrow_at = ctx->coop_narrow_at;
     // a small job behind a kernel that is still running: the 256-thread form, one workgroup per CU, on one of four lanes (see Lane)
     bool pipelined = false;
@@ -2336,7 +2332,7 @@ rsrt_status rsrt_cast_rays(rsrt_context *ctx, uint32_t n, const float *origins, 
         const size_t smem = (size_t)sc.lds_float4s * sizeof(float4) + (trav == 4 ? (size_t)sc.stack_entries * RT_BLOCK * sizeof(uint32_t) : 0u) + coop_lds; // (only the stack walk has a stack)
         if (smem > 160 * 1024) { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); (void)hipFree(d_g); return fail(ctx, RSRT_ERR_INVALID_ARGUMENT, "cast_rays: needs %zu bytes of LDS", smem); }
         uint32_t repeat = ctx->probe_repeat;
-        void *kargs[] = {&sc, &n, &d_o, &d_d, &mode, &flags, &repeat, &d_h, &d_g, &ctx->coop_lds_cap, &ctx->coop_lifo_at, &ctx->coop_narrow_at, &ctx->coop_leaf_quorum}; // (the last three: the cooperative walk's probe only)
+        void *kargs[] = {&sc, &n, &d_o, &d_d, &mode, &flags, &repeat, &d_h, &d_g, &ctx->coop_lds_cap, &ctx->coop_lifo_at, &ctx->coop_narrow_at}; // (the last three: the cooperative walk's probe only)
         e = hipLaunchKernel(probe_function(sv, trav), dim3(n_blocks), dim3(RT_BLOCK), kargs, smem, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -34,7 +34,8 @@
 #pragma once
 #include "rt_device.h"
 
-#define RT_COOP_NCAP 384u   // node-queue entries in LDS (a ring)
+#define RT_COOP_NCAP 320u   // node-queue entries in LDS (a ring): 63 may wait, one node trip adds at most 4 x 64
+#define RT_COOP_MAP 64u     // dwords of the leaf trip's map: 128 records x 16 bits
 #define RT_COOP_LCAP 320u   // leaf-stack entries in LDS: 63 may wait, one node trip adds at most 4 x 64; the pool kernel's compaction list lives here too
 #define RT_COOP_GCAP 4096u  // node items a wave may spill to its arena block
 #define RT_COOP_MIN_LDS_CAP 320u // (run-time cap of the LDS part, tests: 63 + 256 must fit after the spills)
@@ -63,9 +64,9 @@ enum CoopFlags : uint32_t {
     CF_ALL = CF_TIE | CF_SLOW_E | CF_SLOW_S
 };
 
-RT_DEV uint32_t coop_lanes_below(unsigned long long m)
+RT_DEV uint32_t coop_lanes_below(unsigned long long m, uint32_t base = 0u) // base + how many lanes below this one are in m (the count starts AT base: no add)
 {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
 }
 // can the walk take this ray?  1/d by the short reciprocal (exactly the IEEE quotient there, rt_math.h) and finite, origin finite
 RT_DEV bool coop_ray_ok(V3 o, V3 d)
@@ -78,13 +79,18 @@ RT_DEV bool coop_ray_ok(V3 o, V3 d)
 // The wave's two lists.  Every member is wave-uniform (scalar registers): counts come from ballots.
 struct CoopStacks {
     uint32_t *ns, *ls, *gs; // node queue (LDS ring of RT_COOP_NCAP entries), leaf stack (LDS), the node queue's overflow (global, this wave's arena block)
+    uint16_t *map;          // the leaf trip's map (LDS, 128 entries): which item, which of its records, each test slot takes
     uint32_t ns_h, ns_n;    // the ring's head (oldest item) and fill
     uint32_t ls_n, gs_n;
     uint32_t lds_cap, lifo_at, narrow_at;
-    uint32_t leaf_quorum; // a leaf trip hands its stragglers back once fewer than this percentage of the wave's lanes still hold records (0: never)
     RT_DEV uint32_t ring(uint32_t i) const // the ring's i-th entry, counted from the head (i < 2 * RT_COOP_NCAP - head)
     {
         const uint32_t k = ns_h + i;
+        return k >= RT_COOP_NCAP ? k - RT_COOP_NCAP : k;
+    }
+    RT_DEV uint32_t ring_new(unsigned long long m) const // where this lane's new entry goes: behind the fill, one place per lane of m
+    {
+        const uint32_t k = coop_lanes_below(m, ns_h + ns_n);
         return k >= RT_COOP_NCAP ? k - RT_COOP_NCAP : k;
     }
 };
@@ -108,9 +114,9 @@ RT_DEV void coop_push_rays(uint32_t *W, CoopStacks &st, bool valid, uint32_t slo
         if (want_e) { W[C::BEST + 2u * slot] = 0u; W[C::BEST + 2u * slot + 1u] = as_u(RT_INFINITY); }
     }
     const unsigned long long be = __ballot(push_e), bs = __ballot(push_s);
-    if (push_e) st.ns[st.ring(st.ns_n + coop_lanes_below(be))] = slot << 25;
+    if (push_e) st.ns[st.ring_new(be)] = slot << 25;
     st.ns_n += (uint32_t)__popcll(be);
-    if (push_s) st.ns[st.ring(st.ns_n + coop_lanes_below(bs))] = (slot << 25) | RT_COOP_KIND;
+    if (push_s) st.ns[st.ring_new(bs)] = (slot << 25) | RT_COOP_KIND;
     st.ns_n += (uint32_t)__popcll(bs);
 }
 
@@ -133,6 +139,55 @@ RT_DEV float coop_test_other(const View &S, uint32_t rec, uint32_t type, const f
     return plane_t(o, d, v3(r[0].x, r[0].y, r[0].z), v3(r[1].x, r[1].y, r[1].z), v3(r[2].x, r[2].y, r[2].z), v3(r3.x, r3.y, r3.z));
 }
 
+// The test passes of a leaf trip: lane p tests record p of the trip's dense sequence (N = 2: and record p + 64).  map[p] = lane that popped the
+// record's item | which of the item's records << 6; the popped items are still where they were, `top` entries up the leaf stack.
+template <uint32_t POOL, uint32_t N, class View>
+RT_DEV void coop_test_records(DBG_DECL const View &S, uint32_t *W, const CoopStacks &st, uint32_t top, uint32_t n_tests, uint32_t lane, uint32_t &work)
+{
+    typedef CoopCols<POOL> C;
+    bool on[N];
+    uint32_t e[N], item[N], rec[N];
+    float4 r[N][3];
+#pragma unroll
+    for (uint32_t h = 0; h < N; h++) {
+        on[h] = 64u * h + lane < n_tests;
+        e[h] = st.map[on[h] ? 64u * h + lane : 0u];
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < N; h++) item[h] = st.ls[top - (e[h] & 63u)]; // (still there: nothing is pushed during a leaf trip)
+#pragma unroll
+    for (uint32_t h = 0; h < N; h++) {
+        rec[h] = on[h] ? ((item[h] >> 3) & (RT_COOP_MAX_RECORDS - 1u)) + (e[h] >> 6) : 0u;
+        S.template prim_rec<3>(rec[h], r[h]);
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < N; h++) {
+        const uint32_t slot = item[h] >> 25;
+        const bool shadow = (item[h] & RT_COOP_KIND) != 0u;
+        const uint32_t dcol = shadow ? C::S : C::E;
+        const V3 o = v3(as_f(W[C::O + slot]), as_f(W[C::O + POOL + slot]), as_f(W[C::O + 2u * POOL + slot]));
+        const V3 d = v3(as_f(W[dcol + slot]), as_f(W[dcol + POOL + slot]), as_f(W[dcol + 2u * POOL + slot]));
+        const float best_t = as_f(W[C::BEST + 2u * slot + 1u]); // (a filter only: the atomic decides)
+        DBG_WAVE_TICK(12);
+        DBG_ADD(13, on[h] ? 1 : 0);
+        work += on[h] ? 1u : 0u;
+        const uint32_t ty = as_u(r[h][0].w) & 3u;
+        float u, v;
+        float t = triangle_t(o, d, v3(r[h][0].x, r[h][0].y, r[h][0].z), v3(r[h][1].x, r[h][1].y, r[h][1].z), v3(r[h][2].x, r[h][2].y, r[h][2].z), u, v);
+        if (ty != PRIM_TRIANGLE) t = coop_test_other(S, rec[h], ty, r[h], o, d);
+        // a record that repeats an earlier record of its leaf bit for bit can never win (the reference keeps the first of equals):
+        // the upload marks it (r2.w), it counts as a miss — otherwise every hit of doubled geometry would be a tie
+        if (!on[h] || (as_u(r[h][2].w) & 1u) != 0u) t = RT_NO_HIT;
+        if (shadow) {
+            if (t >= 0.0f) atomicOr(&W[C::CT + slot], (uint32_t)CF_OCCLUDED);
+        } else if ((t >= 0.0f) & (t <= best_t)) {
+            unsigned long long *const cell = reinterpret_cast<unsigned long long *>(W + C::BEST + 2u * slot);
+            const unsigned long long old = atomicMin(cell, ((unsigned long long)as_u(t) << 32) | rec[h]);
+            if (((uint32_t)(old >> 32) == as_u(t)) & ((uint32_t)old != rec[h])) atomicOr(&W[C::CT + slot], (uint32_t)CF_TIE);
+        }
+    }
+}
+
 // Runs the stacks dry.  W: the wave's hot columns (CoopCols<POOL>); `work` += node items + records tested by this lane.
 template <uint32_t POOL, class View>
 RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool anyhit_shadow, uint32_t lane, uint32_t &work)
@@ -150,78 +205,43 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (st.ls_n >= 64u || (st.ns_n == 0u && st.gs_n == 0u && st.ls_n != 0u)) {
-            // ---------------- leaf trip: one leaf item a lane, its records two at a time
-            DBG_WAVE_TICK(14); // (diagnostic build: 14 / 28 leaf trips and their items, 12 / 13 record-loop trips and tests, 10 / 11 node trips and items)
-            const uint32_t n_take = min(st.ls_n, 64u);
+            // ---------------- leaf trip: up to 128 RECORDS, one a lane and pass, of as many leaf items as hold them
+            // Leaves hold 1-8 records (suzanne: 1-5, a fifth of them five).  One item a lane left the lanes with short leaves idle while the
+            // long ones were worked off (60 % of the test slots used, profiles/r04_coop_walk.txt); so the items are spread out first: every
+            // lane pops an item, an exclusive prefix sum of the record counts (four ballots: the counts are 4-bit numbers) gives each item its
+            // place in a dense sequence of records, the items whose records end within the first 128 are taken — a run from the top of the
+            // stack, the rest stays — and each writes "record j of the item lane i popped" into the map at its places.  Then lane p tests
+            // record p (and p + 64): whichever item it belongs to, whichever ray.
+            DBG_WAVE_TICK(14); // (diagnostic build: 14 / 28 leaf trips and their items, 12 / 13 test passes and records, 10 / 11 node trips and items)
+            const uint32_t n_take = min(st.ls_n, 64u), top = st.ls_n - 1u;
             const bool act0 = lane < n_take;
-            const uint32_t item = st.ls[act0 ? st.ls_n - 1u - lane : 0u];
-            st.ls_n -= n_take;
-            const uint32_t slot = item >> 25;
-            const bool shadow = (item & RT_COOP_KIND) != 0u;
-            const uint32_t ct = W[C::CT + slot];
-            const uint32_t dcol = shadow ? C::S : C::E;
-            const V3 o = v3(as_f(W[C::O + slot]), as_f(W[C::O + POOL + slot]), as_f(W[C::O + 2u * POOL + slot]));
-            const V3 d = v3(as_f(W[dcol + slot]), as_f(W[dcol + POOL + slot]), as_f(W[dcol + 2u * POOL + slot]));
-            float best_t = as_f(W[C::BEST + 2u * slot + 1u]); // (a filter only: the atomic decides)
-            unsigned long long *const cell = reinterpret_cast<unsigned long long *>(W + C::BEST + 2u * slot);
-            uint32_t rec = (item >> 3) & (RT_COOP_MAX_RECORDS - 1u);
-            // a shadow ray that is already occluded needs nothing more (any hit: only did_hit is read)
-            uint32_t left = (act0 & !(shadow & anyhit_shadow & ((ct & CF_OCCLUDED) != 0u))) ? (item & 7u) + 1u : 0u;
-            const uint32_t n_started = (uint32_t)__popcll(__ballot(left != 0u));
-            DBG_ADD(28, left != 0u ? 1 : 0); DBG_ADD(29, act0 ? 1 : 0);
-            // (a wave-uniform loop: every lane stays until the wave is through, so that the stack's fill — a scalar — is only ever changed by
-            // all lanes together; a lane without records sits the trips out)
-            for (;;) {
-                const unsigned long long more = __ballot(left != 0u);
-                if (more == 0ull) break;
-                // Leaves hold 1-5 records (a fifth of them five): the third pair trip would run for a fifth of the lanes.  Once fewer than
-                // leaf_quorum percent of the lanes that came in with records still hold some, what they hold goes back on the stack as items of
-                // its own — to be tested in a later, fuller trip — and this trip ends.  (Never before the first pair trip: an item shrinks each
-                // time round; a lane's leftover is part of one leaf: the stack's bound stands.)
-                if ((uint32_t)__popcll(more) * 100u < n_started * st.leaf_quorum) {
-                    if (left != 0u) st.ls[st.ls_n + coop_lanes_below(more)] = (item & RT_COOP_HEAD) | (rec << 3) | (left - 1u);
-                    st.ls_n += (uint32_t)__popcll(more);
-                    break;
-                }
-                if (left == 0u) continue;
-                DBG_WAVE_TICK(12);
-                DBG_ADD(13, left >= 2u ? 2 : 1);
-                const bool two = left >= 2u;
-                work += two ? 2u : 1u;
-                const uint32_t rec_a = rec, rec_b = two ? rec + 1u : rec;
-                float4 ra[3], rb[3];
-                S.template prim_rec<3>(rec_a, ra);
-                S.template prim_rec<3>(rec_b, rb);
-                const uint32_t ty_a = as_u(ra[0].w) & 3u, ty_b = as_u(rb[0].w) & 3u;
-                float u, v;
-                float ta = triangle_t(o, d, v3(ra[0].x, ra[0].y, ra[0].z), v3(ra[1].x, ra[1].y, ra[1].z), v3(ra[2].x, ra[2].y, ra[2].z), u, v);
-                float tb = triangle_t(o, d, v3(rb[0].x, rb[0].y, rb[0].z), v3(rb[1].x, rb[1].y, rb[1].z), v3(rb[2].x, rb[2].y, rb[2].z), u, v);
-                if (ty_a != PRIM_TRIANGLE) ta = coop_test_other(S, rec_a, ty_a, ra, o, d);
-                if (ty_b != PRIM_TRIANGLE) tb = coop_test_other(S, rec_b, ty_b, rb, o, d);
-                // a record that repeats an earlier record of its leaf bit for bit can never win (the reference keeps the first of equals):
-                // the upload marks it (r2.w), it counts as a miss — otherwise every hit of doubled geometry would be a tie
-                if ((as_u(ra[2].w) & 1u) != 0u) ta = RT_NO_HIT;
-                if (!two || (as_u(rb[2].w) & 1u) != 0u) tb = RT_NO_HIT;
-                if (shadow) {
-                    if ((ta >= 0.0f) | (tb >= 0.0f)) {
-                        atomicOr(&W[C::CT + slot], (uint32_t)CF_OCCLUDED);
-                        if (anyhit_shadow) left = 0u;
-                    }
-                } else {
-                    if ((ta >= 0.0f) & (ta <= best_t)) {
-                        const unsigned long long old = atomicMin(cell, ((unsigned long long)as_u(ta) << 32) | rec_a);
-                        if (((uint32_t)(old >> 32) == as_u(ta)) & ((uint32_t)old != rec_a)) atomicOr(&W[C::CT + slot], (uint32_t)CF_TIE);
-                        best_t = ta;
-                    }
-                    if ((tb >= 0.0f) & (tb <= best_t)) {
-                        const unsigned long long old = atomicMin(cell, ((unsigned long long)as_u(tb) << 32) | rec_b);
-                        if (((uint32_t)(old >> 32) == as_u(tb)) & ((uint32_t)old != rec_b)) atomicOr(&W[C::CT + slot], (uint32_t)CF_TIE);
-                        best_t = tb;
-                    }
-                }
-                rec += 2u;
-                left = left > 2u ? left - 2u : 0u;
+            uint32_t n_rec;
+            {
+                const uint32_t item = st.ls[act0 ? top - lane : 0u];
+                const bool shadow = (item & RT_COOP_KIND) != 0u;
+                const uint32_t ct = W[C::CT + (item >> 25)];
+                // a shadow ray that is already occluded needs nothing more (any hit: only did_hit is read): its item is popped and dropped
+                n_rec = (act0 & !(shadow & anyhit_shadow & ((ct & CF_OCCLUDED) != 0u))) ? (item & 7u) + 1u : 0u;
             }
+            DBG_ADD(28, n_rec != 0u ? 1 : 0); DBG_ADD(29, act0 ? 1 : 0);
+            uint32_t first = 0u; // records of the lanes below
+#pragma unroll
+            for (uint32_t b = 0; b < 4u; b++) first += coop_lanes_below(__ballot(((n_rec >> b) & 1u) != 0u)) << b;
+            const bool taken = act0 & (first + n_rec <= 128u); // (a run of lanes from 0: the prefix sums only grow; lane 0 always)
+            const uint32_t n_pop = (uint32_t)__popcll(__ballot(taken));
+            const uint32_t n_tests = (uint32_t)__builtin_amdgcn_readlane((int)(first + n_rec), (int)(n_pop - 1u));
+            st.ls_n -= n_pop;
+            for (uint32_t j = 0; j < 8u; j++) { // (wave-uniform: as many rounds as the longest leaf taken has records)
+                const bool w = taken & (j < n_rec);
+                if (__ballot(w) == 0ull) break;
+                if (w) st.map[first + j] = (uint16_t)(lane | (j << 6));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // (both records of a lane are fetched before the first is tested: two passes of one record each would wait for memory twice)
+            if (n_tests > 64u) coop_test_records<POOL, 2u>(DBG_ARG S, W, st, top, n_tests, lane, work);
+            else coop_test_records<POOL, 1u>(DBG_ARG S, W, st, top, n_tests, lane, work);
             COOP_STAMP(26);
             continue;
         }
@@ -289,7 +309,7 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (bi[k] != 0ull) {
-                if (((im >> k) & 1u) != 0u) st.ns[st.ring(st.ns_n + coop_lanes_below(bi[k]))] = head | (child0 + (uint32_t)k);
+                if (((im >> k) & 1u) != 0u) st.ns[st.ring_new(bi[k])] = head | (child0 + (uint32_t)k);
                 st.ns_n += (uint32_t)__popcll(bi[k]);
             }
         }
@@ -299,7 +319,7 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
             const uint32_t m = ((hm >> k) & 1u) != 0u ? as_u(n[4 + k].w) : 0u;
             const unsigned long long bl = __ballot(m != 0u);
             if (bl != 0ull) {
-                if (m != 0u) st.ls[st.ls_n + coop_lanes_below(bl)] = head | ((rec_base + (uint32_t)__builtin_ctz(m)) << 3) | ((uint32_t)__popc(m) - 1u);
+                if (m != 0u) st.ls[coop_lanes_below(bl, st.ls_n)] = head | ((rec_base + (uint32_t)__builtin_ctz(m)) << 3) | ((uint32_t)__popc(m) - 1u);
                 st.ls_n += (uint32_t)__popcll(bl);
             }
         }

@@ -82,7 +82,7 @@ enum PoolStage { ST_GEN = 0, ST_TRACE = 1, ST_MISS = 2, ST_SHADE = 3, ST_FINISH 
 // TRAV 6, the walk's node stack; and in the arena: its cold columns and, TRAV 6, the node stack's overflow block
 __host__ __device__ constexpr uint32_t pool_hot_columns(int trav) { return trav == 6 ? 12u : (uint32_t)H_COUNT; }
 __host__ __device__ constexpr uint32_t pool_list_dwords(int trav) { return trav == 6 ? RT_COOP_LCAP : 64u; }
-__host__ __device__ constexpr uint32_t pool_wave_lds_dwords(int trav, uint32_t pool) { return pool_hot_columns(trav) * pool + pool_list_dwords(trav) + (trav == 6 ? RT_COOP_NCAP : 0u); }
+__host__ __device__ constexpr uint32_t pool_wave_lds_dwords(int trav, uint32_t pool) { return pool_hot_columns(trav) * pool + pool_list_dwords(trav) + (trav == 6 ? RT_COOP_NCAP + RT_COOP_MAP : 0u); }
 __host__ __device__ constexpr uint32_t pool_wave_cold_dwords(int trav, uint32_t pool) { return pool_cold_columns(trav) * pool + (trav == 6 ? RT_COOP_GCAP : 0u); }
 template <uint32_t POOL, int TRAV>
 struct PoolLayout {
@@ -365,8 +365,9 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
             if constexpr (kCoop) {
                 CoopStacks cs;
                 cs.ns = list + L::kListDwords; cs.ls = list; cs.gs = G + L::kColdColumns * POOL;
+                cs.map = reinterpret_cast<uint16_t *>(cs.ns + RT_COOP_NCAP);
                 cs.ns_h = cs.ns_n = cs.ls_n = cs.gs_n = 0u;
-                cs.lds_cap = P.coop_lds_cap; cs.lifo_at = P.coop_lifo_at; cs.narrow_at = P.coop_narrow_at; cs.leaf_quorum = P.coop_leaf_quorum;
+                cs.lds_cap = P.coop_lds_cap; cs.lifo_at = P.coop_lifo_at; cs.narrow_at = P.coop_narrow_at;
                 for (uint32_t i0 = 0; i0 < best_n; i0 += 64u) { // (the list is read to the end before the first leaf item lands in the same words)
                     const bool valid = i0 + lane < best_n;
                     const uint32_t s = list[valid ? i0 + lane : 0u];
