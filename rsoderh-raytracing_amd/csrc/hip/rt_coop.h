@@ -241,7 +241,7 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // (both records of a lane are fetched before the first is tested: two passes of one record each would wait for memory twice)
             if (n_tests > 64u) coop_test_records<POOL, 2u>(DBG_ARG S, W, st, top, n_tests, lane, work);
-            else coop_test_records<POOL, 1u>(DBG_ARG S, W, st, top, n_tests, lane, work);
+            else if (n_tests != 0u) coop_test_records<POOL, 1u>(DBG_ARG S, W, st, top, n_tests, lane, work); // (0: every item popped was a dropped one)
             COOP_STAMP(26);
             continue;
         }

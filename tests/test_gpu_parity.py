@@ -815,6 +815,73 @@ def test_cooperative_walk_spills_and_narrow_trips_do_not_change_the_image(lds_ca
         s2.close()
 
 
+def _merge_sibling_leaves(nodes, limit=8):
+    """The same BVH with every pair of sibling leaves that together hold <= `limit` records merged into their parent (repeatedly): a valid
+    foreign BVH in the reference's layout (pre-order, first child = i + 1) whose leaves hold up to `limit` records."""
+    out = []
+
+    def leaf_run(i):  # (first record, count) if the subtree at i can be ONE leaf of <= limit records, else None
+        n = nodes[i]
+        if n["primitives_len"] > 0:
+            return int(n["primitives_or_second_child_index"]), int(n["primitives_len"])
+        a, b = leaf_run(i + 1), leaf_run(int(n["primitives_or_second_child_index"]))
+        if a and b and a[0] + a[1] == b[0] and a[1] + b[1] <= limit:
+            return a[0], a[1] + b[1]
+        return None
+
+    def emit(i):
+        me = len(out)
+        out.append(nodes[i].copy())
+        run = leaf_run(i)
+        if run:
+            out[me]["primitives_or_second_child_index"], out[me]["primitives_len"], out[me]["split_axis"] = run[0], run[1], 0
+            return
+        emit(i + 1)
+        out[me]["primitives_or_second_child_index"] = len(out)
+        emit(int(nodes[i]["primitives_or_second_child_index"]))
+
+    import sys
+    sys.setrecursionlimit(10000)
+    emit(0)
+    return np.array(out, nodes.dtype)
+
+
+def test_cooperative_walk_with_leaves_of_up_to_eight_records(big_env, monkeypatch):
+    """A leaf trip of the cooperative walk (rt_coop.h) spreads the records of the items it pops over the lanes by a prefix sum of their record
+    counts — 4-bit numbers, 1..8.  The reference's builder stops at five records a leaf; a foreign BVH may hold eight: suzanne's tree with sibling
+    leaves merged while they fit (leaves of 6, 7 and 8 records appear, the count's fourth bit is set), through the walk (RSRT_FLAT=0 keeps the flat
+    loop out) and the probe, bit for bit against the oracle."""
+    monkeypatch.setenv("RSRT_TRAVERSAL", "6")
+    monkeypatch.setenv("RSRT_FLAT", "0")
+    base = R.Scene.load_toml(util.scene_path("suzanne"))
+    nodes = _merge_sibling_leaves(base.bvh_nodes)
+    lens = nodes["primitives_len"][nodes["primitives_len"] > 0]
+    assert lens.max() == 8 and {6, 7, 8} <= set(int(x) for x in lens) and lens.sum() == len(base.primitives)
+    depth = 0
+    stack = [(0, 1)]
+    while stack:
+        i, dd = stack.pop()
+        depth = max(depth, dd)
+        if nodes[i]["primitives_len"] == 0:
+            stack += [(i + 1, dd + 1), (int(nodes[i]["primitives_or_second_child_index"]), dd + 1)]
+    sc = R.Scene(base.materials, base.spheres, base.plane_descs, base.vertices, base.normals, base.triangles, base.camera_desc,
+                 planes=base.planes, primitives=base.primitives, bvh_nodes=nodes, bvh_depth=depth)
+    ref, ost = oracle.render(util.oracle_scene(sc), util.oracle_env(big_env), sc.camera_uniform().view(oracle.CAMERA), 96, 64, 0, 3, 10)
+    img, st = gpu_render(sc, big_env, 96, 64, 0, 3, 10)
+    assert np.array_equal(util.bits(img), util.bits(ref))
+    assert (st["ext_rays"], st["shadow_rays"]) == (ost["ext_rays"], ost["shadow_rays"])
+    rng = np.random.default_rng(9)
+    o = rng.uniform(-3, 3, (4096, 3)).astype(np.float32) + np.float32([0, 1, 1])
+    d = rng.normal(size=(4096, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    hits = oracle.cast_rays(util.oracle_scene(sc), o, d, 0, 0)
+    s2 = R.State.new(sc, util.small_env(), 16, 16)
+    for mode in (6 << 1, (6 << 1) | 16):
+        got = s2.cast_rays(o, d, mode, 0)
+        assert np.array_equal(np.ascontiguousarray(got).view(np.uint32).reshape(-1, 9), hits.view(np.uint32).reshape(-1, 9)), mode
+    s2.close()
+
+
 @pytest.mark.parametrize("name,w,h,spp,mb", [("house", 128, 72, 6, 8), ("default", 96, 64, 4, 10), ("suzanne", 80, 48, 3, 10)])
 def test_two_pipelines_that_share_only_the_asset_files(name, w, h, spp, mb):
     """Every other image test feeds the oracle the product's OWN preprocessing output (tests/util.py: same BVH, same alias table, same

@@ -47,12 +47,12 @@ if tot:
     print('  cycles per invocation: ' + '  '.join('%s %.0f' % (n, c[16 + i] / max(c[i], 1)) for i, n in enumerate(names)) + '  census %.0f' % (c[22] / max(sum(c[0:5]), 1)))
 if c[14] > 0.5 * c[1] and c[25]:  # the cooperative walk (rt_coop.h): a TRACE call takes every waiting ray
     inv = max(c[1], 1)
-    print('  cooperative walk per TRACE call: %.1f rays (slots), %.1f node trips at %.1f%% of the lanes, %.1f leaf trips at %.1f%%, %.1f record-loop trips at %.1f%% of the PAIR slots' % (
-        c[6] / inv, c[10] / inv, 100 * c[11] / max(64 * c[10], 1), c[14] / inv, 100 * c[28] / max(64 * c[14], 1), c[12] / inv, 100 * c[13] / max(128 * c[12], 1)))
+    print('  cooperative walk per TRACE call: %.1f rays (slots), %.1f node trips at %.1f%% of the lanes, %.1f leaf trips popping %.1f items each, %.1f record passes (64 records each) at %.1f%% of the lanes' % (
+        c[6] / inv, c[10] / inv, 100 * c[11] / max(64 * c[10], 1), c[14] / inv, c[28] / max(c[14], 1), c[12] / inv, 100 * c[13] / max(64 * c[12], 1)))
     print('    items popped: node %.1f%% of the lane slots (%.1f%% of them dropped: shadow rays already occluded), leaf %.1f%% (%.1f%% dropped)' % (
         100 * c[30] / max(64 * c[10], 1), 100 * (1 - c[11] / max(c[30], 1)), 100 * c[29] / max(64 * c[14], 1), 100 * (1 - c[28] / max(c[29], 1))))
     print('    rays handed to the exact fixed-order walk (equal closest t, or a non-finite 1/d): %d of %d (%.4f %%)' % (regions[4], rays, 100.0 * regions[4] / max(rays, 1)))
-    print('    wave cycles: %.0f a node trip, %.0f a leaf trip (%.0f a record-loop trip); node trips %.1f%% / leaf trips %.1f%% of the TRACE stage' % (
+    print('    wave cycles: %.0f a node trip, %.0f a leaf trip (%.0f a record pass); node trips %.1f%% / leaf trips %.1f%% of the TRACE stage' % (
         c[25] / max(c[10], 1), c[26] / max(c[14], 1), c[26] / max(c[12], 1), 100 * c[25] / max(c[17], 1), 100 * c[26] / max(c[17], 1)))
 elif c[15] or c[28]:
     inv = max(c[1], 1)
