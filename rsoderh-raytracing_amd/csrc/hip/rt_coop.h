@@ -7,16 +7,18 @@
 // such a leaf is tested, and the winner is the minimum of (t, visiting rank) whatever the order (rt_device.h, "wide walk").  So here the unit
 // of work is not a ray but an ITEM:
 //     node item  (ray, wide node)          -> four exact box tests; a hit interior child is a new node item, a hit leaf a leaf item
-//     leaf item  (ray, first record, n)    -> n primitive tests (n <= 8: one leaf of the reference's tree)
-// and the wave keeps two lists of them in LDS: a QUEUE of node items (a ring: oldest first) and a stack of leaf items.  A trip pops up to 64
-// items — one per lane, any ray — and pushes what they turn up with wave64 ballots + prefix popcounts (the compaction north_star names, at item
-// granularity).  A lane is idle only when a list holds fewer than 64 items, i.e. at the very end of a batch; there are no rounds, no per-ray
-// stack, nothing to park: every ray of the batch is finished when both lists are empty.  (Two wave votes keep the trips dense: a slot's push is
-// skipped when no lane has it, and a leaf trip hands its stragglers back as items of their own — see the leaf trip.)  Node items go oldest first because that keeps
-// the end of a batch short: the shallow items, whose subtrees take the most trips, are worked off while there is plenty beside them, and what is
-// left at the end are the deep ones, one trip from their leaves (newest first, the last old item's whole subtree was walked alone: 72-78 % of
-// the lanes busy in the node trips instead of 90 %, tools/coop_sim.py and profiles/r04_coop_walk.txt).  The rays live where TRACE's rays always lived, in the pool's hot LDS columns, addressed by
-// slot; a lane reads the ray of its item from there (six LDS dwords) instead of keeping one ray in registers.
+//     leaf item  (ray, first record, n)    -> n primitive tests (n <= 8: one leaf of the binary tree)
+// and the wave keeps two lists of them in LDS: a QUEUE of node items (a ring: oldest first) and a stack of leaf items.  A node trip pops up to
+// 64 items — one per lane, any ray — and pushes what they turn up with wave64 ballots + prefix popcounts (the compaction north_star names, at
+// item granularity; a slot's push is skipped when no lane of the wave has it).  A leaf trip pops up to 64 leaf items and spreads their RECORDS
+// over the lanes (a prefix sum of the record counts: leaves hold 1-8 records, and one item a lane would leave the lanes with short leaves idle):
+// up to 128 records a trip, two a lane, any item, any ray.  A lane is idle only when a list runs low, i.e. at the very end of a batch; there
+// are no rounds, no per-ray stack, nothing to park: every ray of the batch is finished when both lists are empty.  Node items go oldest first
+// because that keeps the end of a batch short: the shallow items, whose subtrees take the most trips, are worked off while there is plenty
+// beside them, and what is left at the end are the deep ones, one trip from their leaves (newest first, the last old item's whole subtree was
+// walked alone: 72-78 % of the lanes busy in the node trips instead of 90 %, tools/coop_sim.py and profiles/r04_coop_walk.txt).  The rays live
+// where TRACE's rays always lived, in the pool's hot LDS columns, addressed by slot; a lane reads the ray of its item from there (six LDS dwords)
+// instead of keeping one ray in registers.
 //
 // Results.  Extension ray: one 64-bit LDS cell per slot, t's bits << 32 | record, folded with ds_min_u64 — accepted t are positive floats,
 // so unsigned order is float order and the cell ends as the closest hit, lowest record among equal t.  The reference wants the lowest

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
     constexpr bool kRngHot = TRAV == 2;
     constexpr uint32_t kTCell = kRngHot ? (uint32_t)H_SX : (uint32_t)H_T; // where the extension ray's t waits for SHADE / MISS
     constexpr bool kFlatVote = kRngHot && kBounceInCt; // a TRACE call may return a flat traversal unfinished
-    constexpr bool kPackedMiss = TRAV == 2; // MISS reads an escaping ray's pmf from the texels' alpha (rt_device.h)
+    constexpr bool kPackedMiss = TRAV == 2 || TRAV == 6; // MISS reads an escaping ray's pmf from the texels' alpha (rt_device.h)
     constexpr bool kGenTrace = TRAV >= 2 && !kCoop; // GEN traces the camera ray it has built (the near-first tree walks, kept for RSRT_FLAG_PRUNE, would spill)
     const DevScene &sc = P.scene;
     if (SV != 0) stage_scene_lds(sc);
@@ -417,8 +417,8 @@ __global__ __launch_bounds__(BLOCK, RT_POOL_WAVES_PER_SIMD) void rt_render_pool_
                 // that does hit a fallback primitive has asked in vain: no scene the reference ships has one outside its BVH.)
                 float env_u, env_v;
                 direction_to_equirectangular_uv(d, env_u, env_v);
-                // (flat kernel: the texel's alpha carries its pmf, no alias-table gather; the walks, a register short of their 128,
-                // keep the gather — tests/test_code_object.py)
+                // (flat kernel and cooperative walk: the texel's alpha carries its pmf, no alias-table gather; the per-lane walks, a register
+                // short of their 128, keep the gather — tests/test_code_object.py)
                 const EnvBilinearFetch sky_fetch = kPackedMiss ? sample_env_bilinear_begin_pmf(P.env, env_u, env_v) : sample_env_bilinear_begin(P.env, env_u, env_v);
                 float sky_pmf = 0.0f;
                 if (!kPackedMiss) sky_pmf = environment_direction_pmf(P.env, env_u, env_v);
