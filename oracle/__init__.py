@@ -81,7 +81,7 @@ def lib(fast=False):
     name = {"libm": "liboracle_libm.so", "ops": "liboracle_ops.so"}.get(fast, "liboracle_fast.so" if fast else "liboracle.so")
     if name in _libs:
         return _libs[name]
-    path = os.path.join(_HERE, name)
+    path = os.path.join(os.environ.get("ORACLE_LIB_DIR") or _HERE, name)  # ORACLE_LIB_DIR: sanitizer builds (tools/sanitize_host.sh)
     marker = os.path.join(_HERE, ".built_fma")
     built_fma = open(marker).read().strip() if os.path.exists(marker) else "1"
     if not os.path.exists(path) or (built_fma == "1" and not _cpu_has_fma()):

@@ -17,7 +17,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = _build.build_host()
+        path = os.environ.get("RSRT_HOST_LIB") or _build.build_host()  # RSRT_HOST_LIB: a sanitizer build (tools/sanitize_host.sh)
         L = C.CDLL(path)
         L.rsrt_scene_load_toml.restype = C.c_int
         L.rsrt_scene_load_toml.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]

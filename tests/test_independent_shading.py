@@ -224,7 +224,10 @@ def test_bsdf_functions_agree_with_an_independent_float64_reading():
     L.orc_bsdf_pdf_local.restype = C.c_float
     L.orc_bsdf_sample.restype = C.c_float
     rng = np.random.default_rng(3)
-    mats = np.concatenate([R.Scene.load_toml(util.scene_path(n)).materials.view(oracle.MATERIAL) for n in ("house", "default")])
+    parts = [R.Scene.load_toml(util.scene_path(n)).materials.view(oracle.MATERIAL) for n in ("house", "default")]
+    mats = np.zeros(sum(len(p) for p in parts), oracle.MATERIAL)  # (np.concatenate would pack the records: 32 bytes instead of the struct's 48)
+    mats[:len(parts[0])], mats[len(parts[0]):] = parts[0], parts[1]
+    assert mats.dtype.itemsize == 48
     checked = 0
     for trial in range(1500):
         m = mats[trial % len(mats):trial % len(mats) + 1]
