@@ -22,3 +22,14 @@ export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktra
 export RSRT_HOST_LIB=$O/librsrt_host.so ORACLE_LIB_DIR=$O OMP_NUM_THREADS=4
 if [ ${#ARGS[@]} -eq 0 ]; then ARGS=(tests/test_host_preprocess.py tests/test_golden.py tests/test_oracle_kat.py tests/test_display.py tests/test_independent_geometry.py tests/test_independent_shading.py tests/test_box_containment.py); fi
 python -m pytest -q -x -m "not gpu" -p no:cacheprovider "${ARGS[@]}"
+
+# Part 2: the HOST pass of librsrt.so (rsrt_api.hip's upload-time code: wide-tree collapse, flat leaves, visiting ranks, partition arithmetic,
+# argument checks) under AddressSanitizer — clang's, so in a process of its own; the device code objects are built as always (-fno-gpu-sanitize)
+# and never run here.  Skipped with SAN_SKIP_HIP=1 (the build takes a minute).
+if [ -z "$SAN_SKIP_HIP" ]; then
+  unset LD_PRELOAD RSRT_HOST_LIB ORACLE_LIB_DIR UBSAN_OPTIONS
+  RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fno-vectorize \
+      -fsanitize=address -fno-gpu-sanitize -shared-libsan -I $R/include -DRSRT_BUILD_ID='"asan-host"' -o $O/librsrt.so $R/rsoderh-raytracing_amd/csrc/hip/rsrt_api.hip
+  LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 RSRT_LIB=$O/librsrt.so python -m pytest -q -x -m "not gpu" -p no:cacheprovider "${ARGS[@]}"
+fi
