@@ -1,7 +1,7 @@
 #!/bin/bash
 # AddressSanitizer + UndefinedBehaviorSanitizer over the CPU code: librsrt_host.so (scene / OBJ / HDR loaders, BVH builder, alias table, PNG / PFM
 # writers) and the oracle, built into /tmp/rsrt_san and driven by the CPU tests that exercise them.  (GPU sanitizers are not available on this
-# pool: the kernels are covered by the parity tests instead.)      bash tools/sanitize_host.sh [pytest args]
+# pool: the kernels are covered by the parity tests instead.)      bash tools/sanitize_host.sh [pytest args | --fuzz [trials] [seed]]
 set -e
 ARGS=("$@")
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -20,6 +20,10 @@ cd $R
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 export RSRT_HOST_LIB=$O/librsrt_host.so ORACLE_LIB_DIR=$O OMP_NUM_THREADS=4
+if [ "${ARGS[0]}" = "--fuzz" ]; then  # the loaders' mutation fuzz under the sanitizers instead of the tests
+  python tools/fuzz_loaders.py ${ARGS[1]:-40000} ${ARGS[2]:-1}
+  exit $?
+fi
 if [ ${#ARGS[@]} -eq 0 ]; then ARGS=(tests/test_host_preprocess.py tests/test_golden.py tests/test_oracle_kat.py tests/test_display.py tests/test_independent_geometry.py tests/test_independent_shading.py tests/test_box_containment.py); fi
 python -m pytest -q -x -m "not gpu" -p no:cacheprovider "${ARGS[@]}"
 
