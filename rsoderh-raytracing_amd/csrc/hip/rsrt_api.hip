@@ -319,7 +319,9 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RenderParams P)
 static constexpr size_t kHybridPoolBytes = (size_t)(1024 / RT_WAVE) * 4u * ((size_t)H_COUNT * RT_WALK_POOL + pool_list_dwords(4));
 static constexpr uint32_t kHybridRoomF4 = (uint32_t)((160 * 1024 - kHybridPoolBytes) / sizeof(float4));
 // ... and of the cooperative walk's kernel (TRAV 6): 128-slot pools with their two work stacks
-#define RT_COOP_POOL 128u
+#ifndef RT_COOP_POOL
+#define RT_COOP_POOL 128u // (build-time A/B: -DRT_COOP_POOL=96u with RSRT_WPS=5 fits a fifth wave per SIMD beside 256-thread workgroups)
+#endif
 static constexpr uint32_t kCoopRoomF4 = (uint32_t)((160 * 1024 - (size_t)(1024 / RT_WAVE) * 4u * pool_wave_lds_dwords(6, RT_COOP_POOL)) / sizeof(float4));
 #include "rt_alias_device.h"
 #include "rt_bvh_device.h"
