@@ -322,7 +322,10 @@ static constexpr uint32_t kHybridRoomF4 = (uint32_t)((160 * 1024 - kHybridPoolBy
 #ifndef RT_COOP_POOL
 #define RT_COOP_POOL 128u // (build-time A/B: -DRT_COOP_POOL=96u with RSRT_WPS=5 fits a fifth wave per SIMD beside 256-thread workgroups)
 #endif
-static constexpr uint32_t kCoopRoomF4 = (uint32_t)((160 * 1024 - (size_t)(1024 / RT_WAVE) * 4u * pool_wave_lds_dwords(6, RT_COOP_POOL)) / sizeof(float4));
+#ifndef RT_COOP_BLOCK
+#define RT_COOP_BLOCK 1024 // threads of the one workgroup a CU holds beside the staged node prefix
+#endif
+static constexpr uint32_t kCoopRoomF4 = (uint32_t)((160 * 1024 - (size_t)(RT_COOP_BLOCK / RT_WAVE) * 4u * pool_wave_lds_dwords(6, RT_COOP_POOL)) / sizeof(float4));
 #include "rt_alias_device.h"
 #include "rt_bvh_device.h"
 
@@ -603,7 +606,7 @@ static const void *variant_function(int kv, int sv, int trav)
 {
     if (kv == 0) return sv == 1 ? reinterpret_cast<const void *>(&rt_render_kernel<true>) : reinterpret_cast<const void *>(&rt_render_kernel<false>);
     if (trav == 6) // the cooperative walk: 128-slot pools; one 1024-thread workgroup per CU beside the staged node prefix, else 256-thread workgroups
-        return sv == 2 ? reinterpret_cast<const void *>(&rt_render_pool_kernel<2, 1024, RT_COOP_POOL, 6>)
+        return sv == 2 ? reinterpret_cast<const void *>(&rt_render_pool_kernel<2, RT_COOP_BLOCK, RT_COOP_POOL, 6>)
                        : (sv == 1 ? reinterpret_cast<const void *>(&rt_render_pool_kernel<1, RT_BLOCK, RT_COOP_POOL, 6>) : reinterpret_cast<const void *>(&rt_render_pool_kernel<0, RT_BLOCK, RT_COOP_POOL, 6>));
     if (sv == 2) return pool_function<2, 1024, RT_WALK_POOL>(trav == 2 ? 1 : trav); // (the flat loop needs the whole image: never asked for here)
     if (kv == 1) return sv == 1 ? pool_function<1, RT_BLOCK, 192>(trav) : pool_function<0, RT_BLOCK, 192>(trav);
@@ -2132,7 +2135,7 @@ rsrt_status rsrt_render(rsrt_context *ctx, const rsrt_camera *camera, uint32_t w
     const int kv_eff = pipelined ? 2 : kv;
     const bool big = kv_eff == 4 && sv == 1 && trav != 6; // one workgroup per CU shares the scene copy
     const uint32_t pool = trav == 6 ? RT_COOP_POOL : (sv == 2 ? RT_WALK_POOL : ((kv_eff == 4 && !big) ? 160u : kVariantPool[kv_eff]));
-    const uint32_t block = (sv == 2 || big) ? 1024u : (uint32_t)RT_BLOCK;
+    const uint32_t block = (sv == 2 && trav == 6) ? (uint32_t)RT_COOP_BLOCK : ((sv == 2 || big) ? 1024u : (uint32_t)RT_BLOCK);
     const size_t scene_bytes = (size_t)P.scene.lds_float4s * sizeof(float4);
     const size_t smem = kv == 0 ? scene_bytes + (size_t)P.scene.stack_entries * RT_BLOCK * sizeof(uint32_t)
                                 : scene_bytes + (size_t)(block / RT_WAVE) * 4u * pool_wave_lds_dwords(trav, pool);

@@ -43,11 +43,15 @@
 #define RT_COOP_MIN_LDS_CAP 320u // (run-time cap of the LDS part, tests: 63 + 256 must fit after the spills)
 #define RT_COOP_NARROW_AT 3072u  // outstanding node items beyond which a wave pops one item a trip: GCAP - 3072 - 256 - 64 >= 3 x (wide levels <= 25)
 #define RT_COOP_LIFO_AT 512u     // ... beyond which it pops the newest 64 instead of the oldest (0: always — the first version, A/B)
-#define RT_COOP_MAX_RECORDS (1u << 21) // a leaf item names its first record in 21 bits
-#define RT_COOP_MAX_NODES (1u << 24)   // a node item names its node in 24 bits
-// item = slot << 25 | kind << 24 | payload (kind 1: the slot's shadow ray); node item payload = wide node, leaf item payload = first record << 3 | (records - 1)
-#define RT_COOP_KIND 0x01000000u
-#define RT_COOP_HEAD 0xff000000u
+#ifndef RT_COOP_SLOT_BITS
+#define RT_COOP_SLOT_BITS 7u // a pool of up to 128 slots (build-time A/B: 8 with -DRT_COOP_POOL=192u -DRT_COOP_BLOCK=768)
+#endif
+// item = slot << RT_COOP_SLOT_SHIFT | kind (1: the slot's shadow ray) | payload; node item payload = wide node, leaf item payload = first record << 3 | (records - 1)
+#define RT_COOP_SLOT_SHIFT (32u - RT_COOP_SLOT_BITS)
+#define RT_COOP_KIND (1u << (RT_COOP_SLOT_SHIFT - 1u))
+#define RT_COOP_HEAD (~(RT_COOP_KIND - 1u))
+#define RT_COOP_MAX_NODES RT_COOP_KIND           // a node item names its node in the 24 (23) bits below the kind bit
+#define RT_COOP_MAX_RECORDS (RT_COOP_KIND >> 3)  // a leaf item names its first record in 21 (20) bits
 
 // the pool's hot columns as the cooperative walk lays them out (dword offsets from the wave's base; POOL slots a column)
 template <uint32_t POOL>
@@ -56,7 +60,7 @@ struct CoopCols {
     static constexpr uint32_t BEST = 9u * POOL; // u64[POOL]: record (low dword) | t bits (high dword) of the extension ray's closest hit
     static constexpr uint32_t CT = 11u * POOL;  // stage tag | flags (rt_wavepool.h CtBits) | the walk's own flags below
     static constexpr uint32_t DWORDS = 12u * POOL;
-    static_assert(POOL <= 128u && (BEST % 2u) == 0u, "7-bit slot ids; 8-byte aligned result cells");
+    static_assert(POOL <= (1u << RT_COOP_SLOT_BITS) && (BEST % 2u) == 0u, "slot ids of RT_COOP_SLOT_BITS bits; 8-byte aligned result cells");
 };
 enum CoopFlags : uint32_t {
     CF_OCCLUDED = 64u,   // == F_OCCLUDED (rt_wavepool.h): the shadow ray has hit something
@@ -97,6 +101,16 @@ struct CoopStacks {
     }
 };
 
+// Room for `n_new` (<= 256) more node items in the ring: the newest go to the arena, 64 items at a time.
+RT_DEV void coop_make_room(CoopStacks &st, uint32_t n_new, uint32_t lane)
+{
+    while (st.ns_n + n_new > st.lds_cap && st.ns_n >= 64u && st.gs_n + 64u <= RT_COOP_GCAP) { // (wave-uniform)
+        st.ns_n -= 64u;
+        st.gs[st.gs_n + lane] = st.ns[st.ring(st.ns_n + lane)];
+        st.gs_n += 64u;
+    }
+}
+
 // Root items for up to 64 slots (one per lane; `valid` lanes name a slot whose tag word `ct` says which rays to trace: F_EXT 16, F_SHADOW 8).
 // Sets up the result cell and the walk's flags; a ray the walk cannot take is flagged for coop_slow_rays instead of being pushed.
 template <uint32_t POOL>
@@ -106,6 +120,7 @@ RT_DEV void coop_push_rays(uint32_t *W, CoopStacks &st, bool valid, uint32_t slo
     const V3 o = v3(as_f(W[C::O + slot]), as_f(W[C::O + POOL + slot]), as_f(W[C::O + 2u * POOL + slot]));
     const V3 de = v3(as_f(W[C::E + slot]), as_f(W[C::E + POOL + slot]), as_f(W[C::E + 2u * POOL + slot]));
     const V3 ds = v3(as_f(W[C::S + slot]), as_f(W[C::S + POOL + slot]), as_f(W[C::S + 2u * POOL + slot]));
+    if (st.ns_n + 128u > st.lds_cap) coop_make_room(st, 128u, coop_lanes_below(~0ull)); // (pools of more than 128 slots: a third chunk of root items may not fit the ring)
     const bool want_e = valid & ((ct & f_ext) != 0u), want_s = valid & ((ct & f_shadow) != 0u);
     const bool push_e = want_e & coop_ray_ok(o, de), push_s = want_s & coop_ray_ok(o, ds);
     if (valid) {
@@ -116,20 +131,10 @@ RT_DEV void coop_push_rays(uint32_t *W, CoopStacks &st, bool valid, uint32_t slo
         if (want_e) { W[C::BEST + 2u * slot] = 0u; W[C::BEST + 2u * slot + 1u] = as_u(RT_INFINITY); }
     }
     const unsigned long long be = __ballot(push_e), bs = __ballot(push_s);
-    if (push_e) st.ns[st.ring_new(be)] = slot << 25;
+    if (push_e) st.ns[st.ring_new(be)] = slot << RT_COOP_SLOT_SHIFT;
     st.ns_n += (uint32_t)__popcll(be);
-    if (push_s) st.ns[st.ring_new(bs)] = (slot << 25) | RT_COOP_KIND;
+    if (push_s) st.ns[st.ring_new(bs)] = (slot << RT_COOP_SLOT_SHIFT) | RT_COOP_KIND;
     st.ns_n += (uint32_t)__popcll(bs);
-}
-
-// Room for `n_new` (<= 256) more node items in the ring: the newest go to the arena, 64 items at a time.
-RT_DEV void coop_make_room(CoopStacks &st, uint32_t n_new, uint32_t lane)
-{
-    while (st.ns_n + n_new > st.lds_cap && st.ns_n >= 64u && st.gs_n + 64u <= RT_COOP_GCAP) { // (wave-uniform)
-        st.ns_n -= 64u;
-        st.gs[st.gs_n + lane] = st.ns[st.ring(st.ns_n + lane)];
-        st.gs_n += 64u;
-    }
 }
 
 // One plane or sphere record (rare inside a mesh's tree): the types the triangle path of the leaf trip does not handle
@@ -164,7 +169,7 @@ RT_DEV void coop_test_records(DBG_DECL const View &S, uint32_t *W, const CoopSta
     }
 #pragma unroll
     for (uint32_t h = 0; h < N; h++) {
-        const uint32_t slot = item[h] >> 25;
+        const uint32_t slot = item[h] >> RT_COOP_SLOT_SHIFT;
         const bool shadow = (item[h] & RT_COOP_KIND) != 0u;
         const uint32_t dcol = shadow ? C::S : C::E;
         const V3 o = v3(as_f(W[C::O + slot]), as_f(W[C::O + POOL + slot]), as_f(W[C::O + 2u * POOL + slot]));
@@ -221,7 +226,7 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
             {
                 const uint32_t item = st.ls[act0 ? top - lane : 0u];
                 const bool shadow = (item & RT_COOP_KIND) != 0u;
-                const uint32_t ct = W[C::CT + (item >> 25)];
+                const uint32_t ct = W[C::CT + (item >> RT_COOP_SLOT_SHIFT)];
                 // a shadow ray that is already occluded needs nothing more (any hit: only did_hit is read): its item is popped and dropped
                 n_rec = (act0 & !(shadow & anyhit_shadow & ((ct & CF_OCCLUDED) != 0u))) ? (item & 7u) + 1u : 0u;
             }
@@ -269,7 +274,7 @@ RT_DEV void coop_trace(DBG_DECL const View &S, uint32_t *W, CoopStacks &st, bool
             st.ns_h = st.ring(n_take);
         }
         st.ns_n -= n_take;
-        const uint32_t slot = item >> 25;
+        const uint32_t slot = item >> RT_COOP_SLOT_SHIFT;
         const bool shadow = (item & RT_COOP_KIND) != 0u;
         const uint32_t ct = W[C::CT + slot];
         const bool act = act0 & !(shadow & anyhit_shadow & ((ct & CF_OCCLUDED) != 0u));
