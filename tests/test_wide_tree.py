@@ -305,3 +305,60 @@ def test_deck_scene_needs_more_stack_than_the_walk_has_registers():
             assert rec < 0
     assert ref["did_hit"].sum() > n // 2
     assert most > 8, most  # the device walk's register stack holds eight
+
+
+def leaf_trip_plan(counts):
+    """One leaf trip of the cooperative walk (rt_coop.h), restated: lane i pops the i-th item from the top of the stack (at most 64); counts[i] is the
+    number of records it brings (0: a shadow ray that is already occluded — popped and dropped); an exclusive prefix sum lays the records out
+    as one sequence; the items whose records END within the first 128 are taken.  Returns (items popped, [(lane, record of the item)] per test slot)."""
+    counts = list(counts[:64])
+    first, acc = [], 0
+    for c in counts:
+        first.append(acc)
+        acc += c
+    taken = [first[i] + counts[i] <= 128 for i in range(len(counts))]
+    n_pop = sum(taken)
+    assert all(taken[:n_pop]) and not any(taken[n_pop:])  # a run of lanes from 0: the prefix sums only grow
+    n_tests = first[n_pop - 1] + counts[n_pop - 1]
+    slots = [None] * n_tests
+    for i in range(n_pop):
+        for j in range(counts[i]):
+            assert slots[first[i] + j] is None
+            slots[first[i] + j] = (i, j)
+    return n_pop, slots
+
+
+def test_leaf_trip_spreads_every_record_exactly_once():
+    """The record-level leaf trip: whatever the stack holds — leaves of 1..8 records, dropped items — every record of every popped item gets exactly
+    one test slot, a trip tests at most 128 records and pops at least one item, what is not taken stays on the stack in order, and the stack runs
+    dry in at most as many trips as it has items."""
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        n_items = int(rng.integers(1, 400))
+        stack = [(k, int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8], p=[0.05, 0.15, 0.15, 0.2, 0.15, 0.2, 0.04, 0.03, 0.03]))) for k in range(n_items)]
+        seen = {}
+        trips = 0
+        n_records = sum(c for _, c in stack)
+        while stack:
+            top = stack[::-1][:64]  # lane 0 takes the newest item
+            n_pop, slots = leaf_trip_plan([c for _, c in top])
+            assert 1 <= n_pop <= len(top) and len(slots) <= 128 and None not in slots
+            if len(top) == 64 and n_pop < 64:
+                assert len(slots) + top[n_pop][1] > 128  # stopped only because the next item would not fit
+            for lane, j in slots:
+                key = (top[lane][0], j)
+                assert key not in seen
+                seen[key] = True
+            stack = stack[:len(stack) - n_pop]  # what is not taken stays where it was
+            trips += 1
+            assert trips <= n_items
+        assert len(seen) == n_records
+    # the totals, on one more stack
+    stack = [(k, int(c)) for k, c in enumerate(rng.integers(0, 9, 500))]
+    total, got = sum(c for _, c in stack), 0
+    while stack:
+        top = stack[::-1][:64]
+        n_pop, slots = leaf_trip_plan([c for _, c in top])
+        got += len(slots)
+        stack = stack[:len(stack) - n_pop]
+    assert got == total
